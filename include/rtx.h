@@ -1,0 +1,211 @@
+/*
+ * rtx.h -- C ABI of librtx_hip.so, the MI355X (gfx950) implementation of
+ * rust-raytracer's ray/scene intersection + Whitted shading hot path.
+ *
+ * Boundary being replaced (reference, /root/reference):
+ *   trait IntersectableScene { get_camera, get_lights, intersects }   src/scene/mod.rs:148-154
+ *   RayTracer::init / set_scene / trace_rays                          src/lib.rs:55,64,257
+ * A per-ray `intersects` across FFI + PCIe is unusable, so the boundary is per
+ * frame (rtx_render*) plus a batched form of `intersects` (rtx_intersect_batch*).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a caller-owned buffer.
+ *   - every function returns an rtx_status; nothing aborts or throws across the
+ *     ABI (the reference panics instead: src/lib.rs:72,275).
+ *   - one rtx_context per host thread / GPU; calls on one context are
+ *     serialised by the caller.
+ *   - primitive id = index into the reference's `Scene.primitives`
+ *     (src/scene/mod.rs:159): file order of blocks with every poly_set reversed
+ *     (src/scene/parser/mod.rs:333-338). A miss is -1.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1u
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARG = 1,   /* NULL pointer, zero size, inconsistent descriptor */
+    RTX_ERR_NO_DEVICE = 2,     /* no HIP device / device index out of range */
+    RTX_ERR_HIP = 3,           /* a HIP runtime call failed; see rtx_last_error */
+    RTX_ERR_NO_SCENE = 4,      /* render/intersect before rtx_scene_set (reference: panic, src/lib.rs:72,275) */
+    RTX_ERR_NOT_BUILT = 5,     /* render/intersect before rtx_build */
+    RTX_ERR_UNSUPPORTED = 6,   /* e.g. depth above RTX_MAX_DEPTH, area lights */
+    RTX_ERR_OUT_OF_MEMORY = 7
+} rtx_status;
+
+#define RTX_MAX_DEPTH 32u             /* recursion depth accepted by rtx_render* */
+#define RTX_MATERIAL_NONE 0xFFFFFFFFu /* absent slot of a poly's material list */
+
+/* Material: src/scene/material.rs:86-94. 14 f32 = 56 bytes. Colours are already
+ * clamped to [0,1] by the parser (parser/mod.rs:111-114 -> material.rs:17-27). */
+typedef struct rtx_material {
+    float diffuse[3];
+    float ambient[3];
+    float specular[3];
+    float emissive[3];   /* parsed, never read by the shading path */
+    float shininess;
+    float transparency;
+} rtx_material;
+
+/* Light: src/scene/mod.rs:19-24,62-120. */
+enum { RTX_LIGHT_POINT = 0, RTX_LIGHT_AREA = 1, RTX_LIGHT_DIRECTIONAL = 2 };
+typedef struct rtx_light {
+    uint32_t type;
+    float a[3];          /* point: pos; area: min (first `position`); directional: dir */
+    float b[3];          /* area: max (second `position`); otherwise unused */
+    float color[3];      /* intensity, clamped to [0,1] */
+} rtx_light;
+
+/* Camera: src/scene/mod.rs:122-129. */
+typedef struct rtx_camera {
+    float pos[3];
+    float view_dir[3];
+    float ortho_up[3];
+    float focal_dist;    /* parsed, unused */
+    float vertical_fov;  /* radians */
+} rtx_camera;
+
+/* Triangle flags (Poly::vertex_normal / vertex_material, shapes/poly.rs:54-55). */
+enum { RTX_TRI_VERTEX_NORMAL = 1, RTX_TRI_VERTEX_MATERIAL = 2 };
+
+/* Flattened scene = what a host-side `impl` produces from `Scene`
+ * (src/scene/mod.rs:156-160). All arrays are host memory, copied by
+ * rtx_scene_set. Triangles and spheres are two arrays; `*_prim_index` gives the
+ * reference primitive index of each element (NULL = triangles 0..n_tris-1 then
+ * spheres n_tris..). The union of both index arrays must be a permutation of
+ * 0..n_tris+n_spheres-1. */
+typedef struct rtx_scene_desc {
+    uint32_t n_tris;
+    const float*    tri_pos;        /* [n_tris][3][3]  vertex positions v0,v1,v2 */
+    const float*    tri_normals;    /* [n_tris][3][3]  vertex normals; may be NULL if no tri has RTX_TRI_VERTEX_NORMAL */
+    const uint32_t* tri_mat;        /* [n_tris][3]     global ids of the poly's de-duplicated material list
+                                                       (poly.materials[0..2], parser/mod.rs:266-291); absent = RTX_MATERIAL_NONE */
+    const uint8_t*  tri_flags;      /* [n_tris]        RTX_TRI_* ; may be NULL (= 0) */
+    const uint32_t* tri_prim_index; /* [n_tris]        may be NULL */
+    uint32_t n_spheres;
+    const float*    sph_center_radius; /* [n_spheres][4] cx,cy,cz,r (axes/lengths are ignored by the reference, sphere.rs:12-17) */
+    const uint32_t* sph_mat;           /* [n_spheres]    global id of materials[0] */
+    const uint32_t* sph_prim_index;    /* [n_spheres]    may be NULL */
+    uint32_t n_materials;
+    const rtx_material* materials;
+    uint32_t n_lights;
+    const rtx_light* lights;
+    rtx_camera camera;
+} rtx_scene_desc;
+
+typedef struct rtx_build_stats {
+    uint32_t n_prims;
+    uint32_t n_nodes;        /* traversal nodes emitted (0 when the exhaustive kernel is used) */
+    uint32_t n_leaves;
+    uint32_t max_depth;      /* deepest traversal-node level */
+    uint32_t uses_bvh;       /* 0: scene is small, exhaustive kernel; 1: LBVH */
+    uint32_t key_bits;       /* Morton key width used */
+    float    build_ms;       /* device time of the whole build */
+    float    upload_ms;      /* host->device copy of the scene arrays in rtx_scene_set */
+} rtx_build_stats;
+
+/* Ray counts follow the reference's definition: one ray = one call of
+ * `scene.intersects` (src/lib.rs:117,232,243,264). `skipped_rays` are rays the
+ * reference traces and then discards because the child would be shaded at depth
+ * 0 (src/lib.rs:232-234 with depth-1 == 0); the GPU does not trace them. */
+typedef struct rtx_render_stats {
+    uint64_t primary_rays;
+    uint64_t shadow_rays;       /* includes continuation rays through transparent hits */
+    uint64_t reflect_rays;
+    uint64_t refract_rays;
+    uint64_t skipped_rays;      /* reference-counted but not traced here */
+    uint64_t shaded_nodes;
+    uint64_t panic_pixels;      /* shaded nodes where the reference would have panicked (poly.rs:84-86,93) */
+    float    render_ms;         /* device time of the frame, scene resident, excludes the copy of the image to the host */
+    float    trace_ms;          /* device time inside the traversal kernels (closest-hit + shadow) */
+    uint32_t trace_launches;    /* number of traversal-kernel launches behind trace_ms */
+    uint32_t batches;           /* pixel batches the frame was split into */
+} rtx_render_stats;
+
+typedef struct rtx_context rtx_context;
+
+/* ---- lifetime ------------------------------------------------------------
+ * No counterpart in the reference (it has no device). */
+int  rtx_abi_version(void);
+int  rtx_create(int device, rtx_context** out_ctx);
+void rtx_destroy(rtx_context* ctx);
+/* Message of the last failing call on `ctx` (or of the last failing rtx_create
+ * when ctx is NULL). Never NULL. */
+const char* rtx_last_error(const rtx_context* ctx);
+
+/* ---- scene ---------------------------------------------------------------
+ * Replaces RayTracer::set_scene (src/lib.rs:64-67): copies the flattened scene
+ * to the device. The camera basis of setup_camera (src/lib.rs:69-84) is
+ * computed per frame because it depends on width/height. */
+int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* scene);
+
+/* Replaces Tree::init (src/scene/bvh.rs:82-113), the reference's `-b` build:
+ * bounds -> Morton keys -> LDS radix sort -> Karras hierarchy -> refit ->
+ * traversal nodes. Results of every query equal the exhaustive loop
+ * Scene::intersects (src/scene/mod.rs:181-201), NOT the reference BVH's
+ * right-wins-ties rule (bvh.rs:134). `stats` may be NULL. */
+int rtx_build(rtx_context* ctx, rtx_build_stats* stats);
+
+/* ---- queries -------------------------------------------------------------
+ * Batched IntersectableScene::intersects (src/scene/mod.rs:153,181-201).
+ * ori3/dir3: [n][3] f32. prim_id: [n] i32 (-1 = Missed). t: [n] f32 (the
+ * `point` of ShapeIntersection::Hit; undefined where prim_id < 0). Host
+ * pointers. */
+int rtx_intersect_batch(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3,
+                        int32_t* prim_id, float* t);
+/* Same with device pointers; runs on the context's stream and returns after
+ * the kernel has been enqueued and synchronised. */
+int rtx_intersect_batch_device(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                               int32_t* d_prim_id, float* d_t);
+/* Same query through the exhaustive device kernel regardless of scene size
+ * (the device restatement of the loop at src/scene/mod.rs:186-199). */
+int rtx_intersect_batch_exhaustive(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3,
+                                   int32_t* prim_id, float* t);
+
+/* Primary rays only: compute_ray (src/lib.rs:96-103) for every pixel, then the
+ * closest hit. Row 0 is the top row of the image, i.e. pixel (x,y) is the ray
+ * through (x, height-y-1) as in trace_rays (src/lib.rs:263). Any of the output
+ * pointers may be NULL. Host pointers: prim_id [h][w], t [h][w], ray_dir [h][w][3]. */
+int rtx_primary_hits(rtx_context* ctx, uint32_t width, uint32_t height,
+                     int32_t* prim_id, float* t, float* ray_dir);
+
+/* ---- frame ---------------------------------------------------------------
+ * Replaces RayTracer::init + trace_rays (src/lib.rs:55,257-277) followed by
+ * Color::as_pixel (src/scene/material.rs:57-63). rgb: host buffer [h][w][3] u8,
+ * row 0 = top row; missed pixels are 0,0,0 (bmp::Image::new default).
+ * `samples` is num_samples (area lights only). `stats` may be NULL. */
+int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+               uint8_t* rgb, rtx_render_stats* stats);
+
+/* Tile-sharded frame for one process per GPU. The image is cut into 8x8-pixel
+ * tiles numbered row-major; this call renders tiles with
+ * (tile_index % world) == rank. d_rgb_tiles is DEVICE memory receiving the
+ * rendered tiles packed in increasing tile order, 8*8*3 bytes per tile (edge
+ * tiles are padded with zeros); capacity must be rtx_tiles_per_rank() tiles.
+ * The image stays on the device so the caller can hand it to a collective. */
+int rtx_render_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+                     uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats);
+/* Number of tiles every rank's slab holds (the maximum over ranks, so slabs
+ * have equal size for an all-gather). */
+uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world);
+/* Scatters gathered slabs ([world][tiles_per_rank][8*8*3] u8, device memory)
+ * into a row-major [h][w][3] image (device memory). */
+int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
+                       const uint8_t* d_slabs, uint8_t* d_rgb);
+
+/* The context's HIP stream as a void* (hipStream_t), for callers that order
+ * their own work (collectives, events) against the library's kernels. */
+void* rtx_stream(rtx_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */
