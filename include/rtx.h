@@ -141,6 +141,12 @@ void rtx_destroy(rtx_context* ctx);
  * when ctx is NULL). Never NULL. */
 const char* rtx_last_error(const rtx_context* ctx);
 
+/* Tuning knobs (no counterpart in the reference):
+ *   "force_mode"   0 = automatic, 1 = exhaustive kernel, 2 = BVH (takes effect at the next rtx_build)
+ *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^22)
+ *   "pool_factor"  retained shading nodes per batch pixel (default 4) */
+int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
+
 /* ---- scene ---------------------------------------------------------------
  * Replaces RayTracer::set_scene (src/lib.rs:64-67): copies the flattened scene
  * to the device. The camera basis of setup_camera (src/lib.rs:69-84) is

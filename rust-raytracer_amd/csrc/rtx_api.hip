@@ -1,0 +1,332 @@
+// rtx_api.hip -- the extern "C" entry points declared in include/rtx.h.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "rtx_internal.h"
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename T>
+int upload(rtx_context* ctx, const T* host, size_t count, T** out) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, std::string("hipMalloc(scene): ") + hipGetErrorString(e));
+    ctx->scene_allocs.push_back(p);
+    if (count && host) {
+        e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_HIP, std::string("hipMemcpy(scene): ") + hipGetErrorString(e));
+    }
+    *out = (T*)p;
+    return RTX_OK;
+}
+
+void free_list(std::vector<void*>& v) {
+    for (void* p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// Device scratch for the host-pointer query entry points.
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    T* get(size_t count) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+};
+
+int check_ready(rtx_context* ctx) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return rtx_fail(ctx, RTX_ERR_NO_SCENE, "no scene has been set (rtx_scene_set)");
+    if (!ctx->built) return rtx_fail(ctx, RTX_ERR_NOT_BUILT, "scene has not been built (rtx_build)");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return RTX_OK;
+}
+}  // namespace
+
+int rtx_fail(rtx_context* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return status;
+}
+
+extern "C" {
+
+int rtx_abi_version(void) { return (int)RTX_ABI_VERSION; }
+
+const char* rtx_last_error(const rtx_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rtx_create(int device, rtx_context** out_ctx) {
+    if (!out_ctx) return rtx_fail(nullptr, RTX_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return rtx_fail(nullptr, RTX_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= count) return rtx_fail(nullptr, RTX_ERR_NO_DEVICE, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return rtx_fail(nullptr, RTX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    rtx_context* ctx = new (std::nothrow) rtx_context();
+    if (!ctx) return rtx_fail(nullptr, RTX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return rtx_fail(nullptr, RTX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out_ctx = ctx;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_list(ctx->scene_allocs);
+    free_list(ctx->build_allocs);
+    free_list(ctx->work_allocs);
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* rtx_stream(rtx_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return RTX_ERR_INVALID_ARG;
+    const std::string k(key);
+    if (k == "force_mode") {
+        if (value < 0 || value > 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "force_mode must be 0, 1 or 2");
+        ctx->opt_force_mode = value;
+        ctx->built = false;   // takes effect at the next rtx_build
+    } else if (k == "batch_pixels") {
+        if (value < 64) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "batch_pixels must be at least 64");
+        ctx->opt_batch_pixels = value;
+    } else if (k == "pool_factor") {
+        if (value < 1 || value > 64) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "pool_factor must be in 1..64");
+        ctx->opt_pool_factor = value;
+        ctx->work_batch = 0;  // workspace is re-sized at the next frame
+    } else {
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "unknown option: " + k);
+    }
+    return RTX_OK;
+}
+
+int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (!d) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor is NULL");
+    const uint64_t n64 = (uint64_t)d->n_tris + d->n_spheres;
+    if (n64 >= (1ull << 28)) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "more than 2^28 primitives");
+    const uint32_t n = (uint32_t)n64;
+    if ((d->n_tris && (!d->tri_pos || !d->tri_mat)) || (d->n_spheres && (!d->sph_center_radius || !d->sph_mat)) ||
+        (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor has a NULL array with a non-zero count");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+
+    // prim_ref: reference primitive id -> (kind, index); the id arrays must form a permutation.
+    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
+        const uint32_t id = d->tri_prim_index ? d->tri_prim_index[i] : i;
+        if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
+        ref[id] = i;
+    }
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+        const uint32_t id = d->sph_prim_index ? d->sph_prim_index[i] : d->n_tris + i;
+        if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
+        ref[id] = i | 0x80000000u;
+    }
+    bool need_normals = false;
+    if (d->tri_flags)
+        for (uint32_t i = 0; i < d->n_tris && !need_normals; ++i) need_normals = (d->tri_flags[i] & RTX_TRI_VERTEX_NORMAL) != 0;
+    if (need_normals && !d->tri_normals) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a triangle has RTX_TRI_VERTEX_NORMAL but tri_normals is NULL");
+
+    free_list(ctx->scene_allocs);
+    free_list(ctx->build_allocs);
+    ctx->has_scene = false;
+    ctx->built = false;
+    const auto t0 = std::chrono::steady_clock::now();
+
+    DevScene s{};
+    s.n_prims = n;
+    s.n_tris = d->n_tris;
+    s.n_spheres = d->n_spheres;
+    s.n_lights = d->n_lights;
+    s.n_materials = d->n_materials;
+    uint32_t* d_ref = nullptr;
+    float *d_pos = nullptr, *d_nrm = nullptr;
+    uint32_t *d_tmat = nullptr, *d_smat = nullptr;
+    uint8_t* d_flags = nullptr;
+    float4* d_sph = nullptr;
+    rtx_material* d_mats = nullptr;
+    DevLight* d_lights = nullptr;
+    int rc;
+#define S_TRY(x) do { rc = (x); if (rc != RTX_OK) { free_list(ctx->scene_allocs); return rc; } } while (0)
+    S_TRY(upload(ctx, ref.data(), n, &d_ref));
+    S_TRY(upload(ctx, d->tri_pos, (size_t)d->n_tris * 9, &d_pos));
+    if (need_normals) S_TRY(upload(ctx, d->tri_normals, (size_t)d->n_tris * 9, &d_nrm));
+    S_TRY(upload(ctx, d->tri_mat, (size_t)d->n_tris * 3, &d_tmat));
+    std::vector<uint8_t> zero_flags;
+    const uint8_t* flags = d->tri_flags;
+    if (!flags) {
+        zero_flags.assign(d->n_tris, 0);
+        flags = zero_flags.data();
+    }
+    S_TRY(upload(ctx, flags, (size_t)d->n_tris, &d_flags));
+    S_TRY(upload(ctx, (const float4*)d->sph_center_radius, (size_t)d->n_spheres, &d_sph));
+    S_TRY(upload(ctx, d->sph_mat, (size_t)d->n_spheres, &d_smat));
+    S_TRY(upload(ctx, d->materials, (size_t)d->n_materials, &d_mats));
+    std::vector<DevLight> lights(d->n_lights);
+    ctx->lights.assign(d->lights, d->lights + d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        DevLight l{};
+        l.type = d->lights[i].type;
+        if (l.type > RTX_LIGHT_DIRECTIONAL) { free_list(ctx->scene_allocs); return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "unknown light type"); }
+        for (int k = 0; k < 3; ++k) {
+            l.a[k] = d->lights[i].a[k];
+            l.b[k] = d->lights[i].b[k];
+            l.color[k] = clamp01(d->lights[i].color[k]);   // Color::init clamps (parser/mod.rs:111-114)
+        }
+        if (l.type == RTX_LIGHT_AREA) s.has_area_light = 1;
+        lights[i] = l;
+    }
+    S_TRY(upload(ctx, lights.data(), lights.size(), &d_lights));
+#undef S_TRY
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope below
+    ctx->has_secondary = false;
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rtx_material& m = d->materials[i];
+        if (m.transparency != 0.0f) s.has_transparent = 1;
+        const float sc = std::sqrt(m.specular[0] * m.specular[0] + m.specular[1] * m.specular[1] + m.specular[2] * m.specular[2]);
+        if (sc > 0.0f || m.transparency > 0.0f || sc != sc || m.transparency != m.transparency) ctx->has_secondary = true;
+    }
+    s.prim_ref = d_ref;
+    s.tri_pos = d_pos;
+    s.tri_nrm = d_nrm;
+    s.tri_mat = d_tmat;
+    s.tri_flags = d_flags;
+    s.sph = d_sph;
+    s.sph_mat = d_smat;
+    s.mats = d_mats;
+    s.lights = d_lights;
+    ctx->ds = s;
+    ctx->camera = d->camera;
+    ctx->build_stats = rtx_build_stats{};
+    ctx->build_stats.upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->has_scene = true;
+    return RTX_OK;
+}
+
+int rtx_build(rtx_context* ctx, rtx_build_stats* stats) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return rtx_fail(ctx, RTX_ERR_NO_SCENE, "no scene has been set (rtx_scene_set)");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rtx_bvh_build(ctx);
+    if (rc != RTX_OK) return rc;
+    if (stats) *stats = ctx->build_stats;
+    return RTX_OK;
+}
+
+int rtx_intersect_batch_device(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                               int32_t* d_prim_id, float* d_t) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (n && (!d_ori3 || !d_dir3 || !d_prim_id)) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "NULL ray or output pointer");
+    rc = rtx_launch_intersect(ctx, n, d_ori3, d_dir3, d_prim_id, d_t, 0);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTX_OK;
+}
+
+static int intersect_host(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3, int32_t* prim_id, float* t, int mode) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (n == 0) return RTX_OK;
+    if (!ori3 || !dir3 || !prim_id) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "NULL ray or output pointer");
+    Scratch sc;
+    float* d_o = sc.get<float>(n * 3);
+    float* d_d = sc.get<float>(n * 3);
+    int32_t* d_p = sc.get<int32_t>(n);
+    float* d_t = sc.get<float>(n);
+    if (!d_o || !d_d || !d_p || !d_t) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(ray batch) failed");
+    RTX_HIP(ctx, hipMemcpyAsync(d_o, ori3, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    RTX_HIP(ctx, hipMemcpyAsync(d_d, dir3, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    rc = rtx_launch_intersect(ctx, n, d_o, d_d, d_p, d_t, mode);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemcpyAsync(prim_id, d_p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) RTX_HIP(ctx, hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTX_OK;
+}
+
+int rtx_intersect_batch(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3, int32_t* prim_id, float* t) {
+    return intersect_host(ctx, n, ori3, dir3, prim_id, t, 0);
+}
+int rtx_intersect_batch_exhaustive(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3, int32_t* prim_id, float* t) {
+    return intersect_host(ctx, n, ori3, dir3, prim_id, t, 1);
+}
+
+int rtx_primary_hits(rtx_context* ctx, uint32_t width, uint32_t height, int32_t* prim_id, float* t, float* ray_dir) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    const size_t np = (size_t)width * height;
+    Scratch sc;
+    int32_t* d_p = prim_id ? sc.get<int32_t>(np) : nullptr;
+    float* d_t = t ? sc.get<float>(np) : nullptr;
+    float* d_d = ray_dir ? sc.get<float>(np * 3) : nullptr;
+    if ((prim_id && !d_p) || (t && !d_t) || (ray_dir && !d_d)) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(hit map) failed");
+    rc = rtx_primary_impl(ctx, width, height, d_p, d_t, d_d);
+    if (rc != RTX_OK) return rc;
+    if (prim_id) RTX_HIP(ctx, hipMemcpy(prim_id, d_p, np * 4, hipMemcpyDeviceToHost));
+    if (t) RTX_HIP(ctx, hipMemcpy(t, d_t, np * 4, hipMemcpyDeviceToHost));
+    if (ray_dir) RTX_HIP(ctx, hipMemcpy(ray_dir, d_d, np * 12, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_render_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+                     uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (world == 0 || rank >= world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rank must be below world");
+    if (!d_rgb_tiles) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb_tiles is NULL");
+    return rtx_render_impl(ctx, width, height, depth, samples, rank, world, d_rgb_tiles, stats);
+}
+
+int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (width == 0 || height == 0 || world == 0 || !d_slabs || !d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "bad argument");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rtx_assemble_impl(ctx, width, height, world, d_slabs, d_rgb);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTX_OK;
+}
+
+int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* rgb,
+               rtx_render_stats* stats) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (!rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rgb is NULL");
+    const size_t slab = (size_t)rtx_tiles_per_rank(width, height, 1) * 64 * 3;
+    const size_t img = (size_t)width * height * 3;
+    Scratch sc;
+    uint8_t* d_tiles = sc.get<uint8_t>(slab);
+    uint8_t* d_img = sc.get<uint8_t>(img);
+    if (!d_tiles || !d_img) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(framebuffer) failed");
+    rc = rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_tiles, stats);
+    if (rc != RTX_OK) return rc;
+    rc = rtx_assemble_impl(ctx, width, height, 1, d_tiles, d_img);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemcpyAsync(rgb, d_img, img, hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTX_OK;
+}
+
+}  // extern "C"

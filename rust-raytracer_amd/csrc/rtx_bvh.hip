@@ -1,0 +1,633 @@
+// rtx_bvh.hip -- GPU build of the linear BVH that replaces the reference's
+// median-split tree (Tree::init / Tree::build, src/scene/bvh.rs:82-113):
+//   bounds (Shape::get_bbox: poly.rs:122-136, sphere.rs:45-52; centroid: shapes/mod.rs:40-42)
+//   -> Morton keys -> LSD radix sort staged through LDS -> Karras hierarchy
+//   -> bottom-up refit (one launch per tree level) -> 64-byte traversal nodes
+//   with small subtrees collapsed into leaves of up to RTX_LEAF_MAX primitives.
+// Queries on the result return what the exhaustive loop returns (see
+// rtx_traverse.h); the reference BVH's own tie rule (bvh.rs:134) is not copied.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "rtx_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSortItems = 16;                       // keys per thread
+constexpr int kSortTile = kThreads * kSortItems;     // 4096 keys per workgroup
+constexpr int kScanChunk = kThreads * 16;
+
+// Order-preserving map f32 -> u32 so that integer atomics implement float min/max.
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+inline float dec_f32(uint32_t e) {
+    const uint32_t b = e ^ ((e >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+struct SceneBounds {   // encoded with enc_f32
+    uint32_t cmin[3], cmax[3];   // centroids
+    uint32_t bmin[3], bmax[3];   // boxes
+};
+
+__device__ __forceinline__ void prim_box(const DevScene& s, uint32_t id, V3& mn, V3& mx) {
+    const uint32_t ref = s.prim_ref[id];
+    const uint32_t idx = ref & 0x7fffffffu;
+    if (ref >> 31) {  // sphere.rs:45-52
+        const float4 sp = s.sph[idx];
+        const V3 c = v3(sp.x, sp.y, sp.z);
+        mn = vmult(v3(-1.0f, -1.0f, -1.0f), sp.w) + c;
+        mx = vmult(v3(1.0f, 1.0f, 1.0f), sp.w) + c;
+    } else {          // poly.rs:122-136
+        const float* p = s.tri_pos + (size_t)idx * 9;
+        mn = v3(fminf(p[0], fminf(p[3], p[6])), fminf(p[1], fminf(p[4], p[7])), fminf(p[2], fminf(p[5], p[8])));
+        mx = v3(fmaxf(p[0], fmaxf(p[3], p[6])), fmaxf(p[1], fmaxf(p[4], p[7])), fmaxf(p[2], fmaxf(p[5], p[8])));
+    }
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_bounds(DevScene s, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                                                      SceneBounds* __restrict__ sb) {
+    const float inf = __builtin_inff();
+    V3 cmn = v3(inf, inf, inf), cmx = v3(-inf, -inf, -inf), amn = cmn, amx = cmx;
+    for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < s.n_prims; id += gridDim.x * kThreads) {
+        V3 mn, mx;
+        prim_box(s, id, mn, mx);
+        bmin[id] = make_float4(mn.x, mn.y, mn.z, 0.0f);
+        bmax[id] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+        const V3 c = vmult(mn, 0.5f) + vmult(mx, 0.5f);  // BoundingBox::centroid, shapes/mod.rs:40-42
+        cmn = v3(fminf(cmn.x, c.x), fminf(cmn.y, c.y), fminf(cmn.z, c.z));
+        cmx = v3(fmaxf(cmx.x, c.x), fmaxf(cmx.y, c.y), fmaxf(cmx.z, c.z));
+        amn = v3(fminf(amn.x, mn.x), fminf(amn.y, mn.y), fminf(amn.z, mn.z));
+        amx = v3(fmaxf(amx.x, mx.x), fmaxf(amx.y, mx.y), fmaxf(amx.z, mx.z));
+    }
+    float lo[6] = {cmn.x, cmn.y, cmn.z, amn.x, amn.y, amn.z};
+    float hi[6] = {cmx.x, cmx.y, cmx.z, amx.x, amx.y, amx.z};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        lo[k] = wave_min(lo[k]);
+        hi[k] = wave_max(hi[k]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&sb->cmin[k], enc_f32(lo[k]));
+            atomicMax(&sb->cmax[k], enc_f32(hi[k]));
+            atomicMin(&sb->bmin[k], enc_f32(lo[3 + k]));
+            atomicMax(&sb->bmax[k], enc_f32(hi[3 + k]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t x) {  // bit i -> bit 3i
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+struct MortonParams {
+    float cmin[3];
+    float scale[3];   // cells per unit length (0 when the extent is 0)
+    float qmax;       // 2^bits - 1
+};
+
+__global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                                                      MortonParams mp, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < n; id += gridDim.x * kThreads) {
+        const float4 a = bmin[id], b = bmax[id];
+        const float cx = a.x * 0.5f + b.x * 0.5f, cy = a.y * 0.5f + b.y * 0.5f, cz = a.z * 0.5f + b.z * 0.5f;
+        const float qx = fminf(fmaxf((cx - mp.cmin[0]) * mp.scale[0], 0.0f), mp.qmax);
+        const float qy = fminf(fmaxf((cy - mp.cmin[1]) * mp.scale[1], 0.0f), mp.qmax);
+        const float qz = fminf(fmaxf((cz - mp.cmin[2]) * mp.scale[2], 0.0f), mp.qmax);
+        keys[id] = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
+        vals[id] = id;
+    }
+}
+
+// ---- exclusive scan over u32 (three launches) ------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// Exclusive scan of one value per thread across a 256-thread workgroup; *total gets the sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds4, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) {
+        const uint32_t t = lds4[k];
+        if (k < w) base += t;
+        sum += t;
+    }
+    if (total) *total = sum;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_partial(const uint32_t* __restrict__ data, uint32_t m, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t base = blockIdx.x * kScanChunk;
+    uint32_t s = 0;
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t i = base + k * kThreads + threadIdx.x;
+        if (i < m) s += data[i];
+    }
+    uint32_t total;
+    block_excl_scan(s, lds4, &total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kThreads) void k_scan_top(uint32_t* __restrict__ partial, uint32_t p) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < p; base += kThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < p) ? partial[i] : 0;
+        uint32_t total;
+        const uint32_t e = block_excl_scan(v, lds4, &total);
+        if (i < p) partial[i] = carry + e;
+        carry += total;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_scan_apply(uint32_t* __restrict__ data, uint32_t m, const uint32_t* __restrict__ partial) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 16;
+    uint32_t v[16];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = (base + k < m) ? data[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t run = block_excl_scan(s, lds4, nullptr) + partial[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (base + k < m) data[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- LSD radix sort, 8-bit digits, staged through LDS ----------------------
+__global__ __launch_bounds__(kThreads) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                         uint32_t* __restrict__ hist, uint32_t nb) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int k = 0; k < kSortItems; ++k) {
+        const uint32_t i = base + k * kThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];   // digit-major: one scan gives every offset
+}
+
+__global__ __launch_bounds__(kThreads) void k_sort_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t n, int shift, const uint32_t* __restrict__ offsets, uint32_t nb) {
+    __shared__ volatile uint32_t whist[4][256];   // volatile: lanes of one wavefront hand counts to each other
+    __shared__ uint32_t dig_excl[256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t lds4[4];
+    __shared__ uint64_t skeys[kSortTile];
+    __shared__ uint32_t svals[kSortTile];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tile = blockIdx.x * kSortTile;
+    for (int k = 0; k < 4; ++k) whist[k][tid] = 0;
+    __syncthreads();
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems];
+    uint16_t rank[kSortItems];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // Each wavefront ranks a contiguous 1024-key chunk in 16 rounds of 64 keys; keys
+    // with equal digits keep their input order (stable), as LSD sorting requires.
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = tile + w * (kSortTile / 4) + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keys_in[i] : ~0ull;
+        val[r] = valid ? vals_in[i] : 0u;
+        const uint32_t dig = (uint32_t)(key[r] >> shift) & 255u;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((dig >> b) & 1u);
+            m &= ((dig >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = __popcll(m & lt_mask);
+        const uint32_t pre = whist[w][dig];
+        rank[r] = (uint16_t)(pre + before);
+        if (valid && before == 0) whist[w][dig] = pre + __popcll(m);
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = whist[k][tid];
+        whist[k][tid] = run;
+        run += t;
+    }
+    const uint32_t ex = block_excl_scan(run, lds4, nullptr);
+    dig_excl[tid] = ex;
+    gbase[tid] = offsets[tid * nb + blockIdx.x] - ex;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = tile + w * (kSortTile / 4) + r * 64 + lane;
+        if (i < n) {
+            const uint32_t dig = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t lp = dig_excl[dig] + whist[w][dig] + rank[r];
+            skeys[lp] = key[r];
+            svals[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = min((uint32_t)kSortTile, n - tile);
+    for (uint32_t i = tid; i < count; i += kThreads) {
+        const uint64_t k = skeys[i];
+        const uint32_t dst = gbase[(uint32_t)(k >> shift) & 255u] + i;
+        keys_out[dst] = k;
+        vals_out[dst] = svals[i];
+    }
+}
+
+// ---- Karras 2012: one internal node per thread ------------------------------
+__device__ __forceinline__ int kdelta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));   // duplicate keys: fall back to the position
+    return __clzll((long long)(a ^ b));
+}
+// Node ids: internal i in [0, n-1) -> i ; leaf j in [0, n) -> (n-1) + j.
+__global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict__ keys, int n, int* __restrict__ child_l,
+                                                      int* __restrict__ child_r, int* __restrict__ parent,
+                                                      int* __restrict__ rng_first, int* __restrict__ rng_last) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (kdelta(keys, n, i, i + 1) - kdelta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = kdelta(keys, n, i, i - d);
+    int lmax = 2;
+    while (kdelta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (kdelta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = kdelta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (kdelta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int left = (lo == gamma) ? (n - 1) + gamma : gamma;
+    const int right = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+    child_l[i] = left;
+    child_r[i] = right;
+    parent[left] = i;
+    parent[right] = i;
+    rng_first[i] = lo;
+    rng_last[i] = hi;
+    if (i == 0) parent[0] = -1;
+}
+
+struct PadParams {
+    float rel;        // boxes grow by rel * (largest |coordinate| of the box)
+    float sphere_k;   // sphere boxes additionally grow to sqrt(r^2 + sphere_k) - r
+};
+
+// Leaves: padded primitive boxes. Padding covers primitive tests that accept a
+// ray passing marginally outside the exact shape (f32 rounding in
+// Moeller-Trumbore; cancellation in the sphere discriminant, which is
+// proportional to the squared distance between ray origin and centre).
+__global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
+                                                         const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                                                         float4* __restrict__ nmin, float4* __restrict__ nmax,
+                                                         const int* __restrict__ parent, uint32_t* __restrict__ counter,
+                                                         uint8_t* __restrict__ theight, int* __restrict__ queue,
+                                                         uint32_t* __restrict__ qcount, PadParams pp) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t id = sorted_ids[j];
+    float4 a = bmin[id], b = bmax[id];
+    float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
+    float pad = pp.rel * m + 1e-30f;
+    const uint32_t ref = s.prim_ref[id];
+    if (ref >> 31) {
+        const float r = fabsf(s.sph[ref & 0x7fffffffu].w);
+        pad += sqrtf(r * r + pp.sphere_k) - r;
+    }
+    const uint32_t node = (n - 1) + j;
+    nmin[node] = make_float4(a.x - pad, a.y - pad, a.z - pad, 0.0f);
+    nmax[node] = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
+    theight[node] = 0;
+    if (n > 1) {
+        const int p = parent[node];
+        if (atomicAdd(&counter[p], 1u) == 1u) queue[atomicAdd(qcount, 1u)] = p;
+    }
+}
+
+// One tree level per launch: every node in `qin` has both children finished by
+// earlier launches, so their boxes are visible without in-kernel fences.
+__global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
+                                                          const int* __restrict__ child_l, const int* __restrict__ child_r,
+                                                          const int* __restrict__ rng_first, const int* __restrict__ rng_last,
+                                                          float4* __restrict__ nmin, float4* __restrict__ nmax,
+                                                          const int* __restrict__ parent, uint32_t* __restrict__ counter,
+                                                          uint8_t* __restrict__ theight, int* __restrict__ qout,
+                                                          uint32_t* __restrict__ qout_count) {
+    const uint32_t cnt = *qin_count;
+    for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += gridDim.x * kThreads) {
+        const int i = qin[k];
+        const int l = child_l[i], r = child_r[i];
+        const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
+        nmin[i] = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), 0.0f);  // BoundingBox + , shapes/mod.rs:86-104
+        nmax[i] = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
+        const int size = rng_last[i] - rng_first[i] + 1;
+        const int h = (size <= RTX_LEAF_MAX) ? 0 : 1 + max((int)theight[l], (int)theight[r]);
+        theight[i] = (uint8_t)min(h, 255);
+        const int p = parent[i];
+        if (p >= 0 && atomicAdd(&counter[p], 1u) == 1u) qout[atomicAdd(qout_count, 1u)] = p;
+    }
+}
+
+__device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
+                                         uint32_t* leaf_count) {
+    if (c >= n - 1) {
+        atomicAdd(leaf_count, 1u);
+        return (int)~(((uint32_t)(c - (n - 1)) << 3) | 0u);
+    }
+    const int size = rng_last[c] - rng_first[c] + 1;
+    if (size <= RTX_LEAF_MAX) {
+        atomicAdd(leaf_count, 1u);
+        return (int)~(((uint32_t)rng_first[c] << 3) | (uint32_t)(size - 1));
+    }
+    return c;
+}
+__global__ __launch_bounds__(kThreads) void k_emit(int n, const int* __restrict__ child_l, const int* __restrict__ child_r,
+                                                    const int* __restrict__ rng_first, const int* __restrict__ rng_last,
+                                                    const float4* __restrict__ nmin, const float4* __restrict__ nmax,
+                                                    BvhNode* __restrict__ nodes, uint32_t* __restrict__ counts) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n - 1) return;
+    const int size = rng_last[i] - rng_first[i] + 1;
+    if (size <= RTX_LEAF_MAX) return;   // absorbed into a leaf of an ancestor
+    const int l = child_l[i], r = child_r[i];
+    const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
+    BvhNode nd;
+    nd.q0 = make_float4(la.x, la.y, la.z, lb.x);
+    nd.q1 = make_float4(lb.y, lb.z, ra.x, ra.y);
+    nd.q2 = make_float4(ra.z, rb.x, rb.y, rb.z);
+    const int lr = child_ref(l, n, rng_first, rng_last, &counts[1]);
+    const int rr = child_ref(r, n, rng_first, rng_last, &counts[1]);
+    nd.q3 = make_float4(__int_as_float(lr), __int_as_float(rr), 0.0f, 0.0f);
+    nodes[i] = nd;
+    atomicAdd(&counts[0], 1u);
+}
+
+// Traversal records, in `order` (sorted ids) or in id order when order == nullptr.
+__global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32_t* __restrict__ order, PrimRec* __restrict__ recs) {
+    for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < s.n_prims; j += gridDim.x * kThreads) {
+        const uint32_t id = order ? order[j] : j;
+        const uint32_t ref = s.prim_ref[id];
+        const uint32_t idx = ref & 0x7fffffffu;
+        PrimRec rc;
+        if (ref >> 31) {
+            const float4 sp = s.sph[idx];
+            rc.q0 = make_float4(sp.x, sp.y, sp.z, __uint_as_float(id));
+            rc.q1 = make_float4(sp.w, 0.0f, 0.0f, __uint_as_float(1u));
+            rc.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            const float* p = s.tri_pos + (size_t)idx * 9;
+            const V3 v0 = v3(p[0], p[1], p[2]);
+            const V3 e1 = v3(p[3], p[4], p[5]) - v0;   // poly.rs:145-146
+            const V3 e2 = v3(p[6], p[7], p[8]) - v0;
+            rc.q0 = make_float4(v0.x, v0.y, v0.z, __uint_as_float(id));
+            rc.q1 = make_float4(e1.x, e1.y, e1.z, __uint_as_float(0u));
+            rc.q2 = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        }
+        recs[j] = rc;
+    }
+}
+
+template <typename T>
+int dev_alloc(rtx_context* ctx, std::vector<void*>& owner, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    owner.push_back(p);
+    *out = (T*)p;
+    return RTX_OK;
+}
+
+inline uint32_t grid_for(uint64_t n, uint32_t cap = 4096) {
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kThreads - 1) / kThreads, cap));
+}
+
+}  // namespace
+
+int rtx_bvh_build(rtx_context* ctx) {
+    DevScene& s = ctx->ds;
+    const uint32_t n = s.n_prims;
+    hipStream_t st = ctx->stream;
+    for (void* p : ctx->build_allocs) (void)hipFree(p);
+    ctx->build_allocs.clear();
+    ctx->built = false;
+    rtx_build_stats bs{};
+    bs.n_prims = n;
+    bs.upload_ms = ctx->build_stats.upload_ms;
+
+    hipEvent_t ev0, ev1;
+    RTX_HIP(ctx, hipEventCreate(&ev0));
+    RTX_HIP(ctx, hipEventCreate(&ev1));
+    RTX_HIP(ctx, hipEventRecord(ev0, st));
+
+    std::vector<void*> tmp;   // freed at the end
+    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); tmp.clear(); };
+#define TRY(x) do { int rc_ = (x); if (rc_ != RTX_OK) { cleanup(); return rc_; } } while (0)
+#define TRY_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); \
+        return rtx_fail(ctx, RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+
+    PrimRec* recs = nullptr;
+    TRY(dev_alloc(ctx, ctx->build_allocs, &recs, n));
+
+    // Scene bounds are needed in both modes (safe region of the padded tests).
+    float4 *bmin = nullptr, *bmax = nullptr;
+    SceneBounds* sb = nullptr;
+    TRY(dev_alloc(ctx, tmp, &bmin, n));
+    TRY(dev_alloc(ctx, tmp, &bmax, n));
+    TRY(dev_alloc(ctx, tmp, &sb, 1));
+    SceneBounds init;
+    for (int k = 0; k < 3; ++k) { init.cmin[k] = init.bmin[k] = 0xFFFFFFFFu; init.cmax[k] = init.bmax[k] = 0u; }
+    TRY_HIP(hipMemcpyAsync(sb, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (n > 0) hipLaunchKernelGGL(k_bounds, dim3(grid_for(n, 1024)), dim3(kThreads), 0, st, s, bmin, bmax, sb);
+    SceneBounds hb;
+    TRY_HIP(hipMemcpyAsync(&hb, sb, sizeof(hb), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    float cmin[3], cmax[3], smin[3], smax[3];
+    for (int k = 0; k < 3; ++k) {
+        cmin[k] = dec_f32(hb.cmin[k]); cmax[k] = dec_f32(hb.cmax[k]);
+        smin[k] = dec_f32(hb.bmin[k]); smax[k] = dec_f32(hb.bmax[k]);
+        if (n == 0) cmin[k] = cmax[k] = smin[k] = smax[k] = 0.0f;
+        ctx->scene_min[k] = smin[k];
+        ctx->scene_max[k] = smax[k];
+    }
+    // Safe region: a cube around the scene that contains the camera with margin.
+    float radius = 0.0f, dcam = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        s.safe_c[k] = 0.5f * smin[k] + 0.5f * smax[k];
+        radius = std::max(radius, 0.5f * (smax[k] - smin[k]));
+        dcam = std::max(dcam, std::fabs(ctx->camera.pos[k] - s.safe_c[k]));
+    }
+    if (!std::isfinite(radius)) radius = 0.0f;
+    if (!std::isfinite(dcam)) dcam = 0.0f;
+    s.safe_r = std::max(std::max(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f);
+    s.pad_rel = 1.0f / 131072.0f;   // 2^-17, about 128 ulp of the coordinate magnitude
+    PadParams pp;
+    pp.rel = s.pad_rel;
+    const float dmax = 1.7320508f * (s.safe_r + radius);   // farthest origin-to-centre distance inside the safe cube
+    pp.sphere_k = (1.0f / 524288.0f) * dmax * dmax;        // 2^-19 * D^2, ~32 roundings of |o - c|^2
+
+    const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > RTX_LEAF_MAX)
+                        : (ctx->opt_force_mode == 1) ? false : (n > RTX_EXHAUSTIVE_MAX);
+    if (!want_bvh) {
+        if (n > 0) hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, (const uint32_t*)nullptr, recs);
+        s.recs = recs;
+        s.nodes = nullptr;
+        s.uses_bvh = 0;
+    } else {
+        // Morton keys: enough bits per axis to separate ~n cells, at most 21.
+        int bits = 4;
+        while (bits < 21 && (1ull << (3 * bits)) < (uint64_t)n * 4096ull) ++bits;
+        bs.key_bits = 3 * bits;
+        MortonParams mp;
+        mp.qmax = (float)((1u << bits) - 1u);
+        for (int k = 0; k < 3; ++k) {
+            const float ext = cmax[k] - cmin[k];
+            mp.cmin[k] = cmin[k];
+            mp.scale[k] = (ext > 0.0f && std::isfinite(ext)) ? (float)(1u << bits) / ext : 0.0f;
+        }
+        uint64_t* keys[2];
+        uint32_t* vals[2];
+        for (int k = 0; k < 2; ++k) { TRY(dev_alloc(ctx, tmp, &keys[k], n)); TRY(dev_alloc(ctx, tmp, &vals[k], n)); }
+        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, mp, keys[0], vals[0]);
+
+        const uint32_t nb = (n + kSortTile - 1) / kSortTile;
+        const uint32_t m = 256u * nb;
+        const uint32_t np = (m + kScanChunk - 1) / kScanChunk;
+        uint32_t *hist = nullptr, *partial = nullptr;
+        TRY(dev_alloc(ctx, tmp, &hist, m));
+        TRY(dev_alloc(ctx, tmp, &partial, np));
+        int cur = 0;
+        for (int shift = 0; shift < 3 * bits; shift += 8) {
+            hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kThreads), 0, st, keys[cur], n, shift, hist, nb);
+            hipLaunchKernelGGL(k_scan_partial, dim3(np), dim3(kThreads), 0, st, hist, m, partial);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kThreads), 0, st, partial, np);
+            hipLaunchKernelGGL(k_scan_apply, dim3(np), dim3(kThreads), 0, st, hist, m, partial);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kThreads), 0, st, keys[cur], vals[cur], keys[cur ^ 1],
+                               vals[cur ^ 1], n, shift, hist, nb);
+            cur ^= 1;
+        }
+        const uint64_t* skeys = keys[cur];
+        const uint32_t* sids = vals[cur];
+
+        int *child_l, *child_r, *parent, *rng_first, *rng_last, *queue[2];
+        uint32_t *counter, *qcount, *counts;
+        uint8_t* theight;
+        float4 *nmin, *nmax;
+        const size_t total = 2 * (size_t)n - 1;
+        TRY(dev_alloc(ctx, tmp, &child_l, n - 1));
+        TRY(dev_alloc(ctx, tmp, &child_r, n - 1));
+        TRY(dev_alloc(ctx, tmp, &rng_first, n - 1));
+        TRY(dev_alloc(ctx, tmp, &rng_last, n - 1));
+        TRY(dev_alloc(ctx, tmp, &parent, total));
+        TRY(dev_alloc(ctx, tmp, &counter, n - 1));
+        TRY(dev_alloc(ctx, tmp, &theight, total));
+        TRY(dev_alloc(ctx, tmp, &nmin, total));
+        TRY(dev_alloc(ctx, tmp, &nmax, total));
+        TRY(dev_alloc(ctx, tmp, &queue[0], n));
+        TRY(dev_alloc(ctx, tmp, &queue[1], n));
+        TRY(dev_alloc(ctx, tmp, &qcount, 2));
+        TRY(dev_alloc(ctx, tmp, &counts, 2));
+        TRY_HIP(hipMemsetAsync(counter, 0, (size_t)(n - 1) * 4, st));
+        TRY_HIP(hipMemsetAsync(qcount, 0, 8, st));
+        TRY_HIP(hipMemsetAsync(counts, 0, 8, st));
+        hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, child_l,
+                           child_r, parent, rng_first, rng_last);
+        hipLaunchKernelGGL(k_leaf_init, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax,
+                           nmin, nmax, parent, counter, theight, queue[0], &qcount[0], pp);
+        // Refit: one launch per level until the queue drains (the root pushes nothing).
+        int q = 0;
+        uint32_t levels = 0;
+        for (;;) {
+            uint32_t cnt = 0;
+            TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipStreamSynchronize(st));
+            if (cnt == 0) break;
+            if (++levels > 4096) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
+            TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
+            hipLaunchKernelGGL(k_refit_pass, dim3(grid_for(cnt)), dim3(kThreads), 0, st, queue[q], &qcount[q], child_l, child_r,
+                               rng_first, rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1]);
+            q ^= 1;
+        }
+        BvhNode* nodes = nullptr;
+        TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
+        TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
+        hipLaunchKernelGGL(k_emit, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, child_l, child_r,
+                           rng_first, rng_last, nmin, nmax, nodes, counts);
+        hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
+        uint32_t hcounts[2] = {0, 0};
+        uint8_t root_h = 0;
+        TRY_HIP(hipMemcpyAsync(hcounts, counts, 8, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipMemcpyAsync(&root_h, theight, 1, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipStreamSynchronize(st));
+        bs.n_nodes = hcounts[0];
+        bs.n_leaves = hcounts[1];
+        bs.max_depth = root_h;
+        s.recs = recs;
+        s.nodes = nodes;
+        s.uses_bvh = 1;
+    }
+    bs.uses_bvh = s.uses_bvh;
+    TRY_HIP(hipEventRecord(ev1, st));
+    TRY_HIP(hipEventSynchronize(ev1));
+    TRY_HIP(hipGetLastError());
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    bs.build_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    cleanup();
+#undef TRY
+#undef TRY_HIP
+    if (s.uses_bvh && bs.max_depth > 120)
+        return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the largest traversal stack");
+    ctx->build_stats = bs;
+    ctx->built = true;
+    return RTX_OK;
+}

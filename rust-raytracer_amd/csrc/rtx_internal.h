@@ -1,0 +1,145 @@
+// rtx_internal.h -- device-side data layout and the context behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_math.h"
+
+// ---------------------------------------------------------------------------
+// Layout in HBM
+//
+// PrimRec (48 B, three 16-B quads): what the traversal kernels fetch per
+// candidate primitive. One record is one contiguous 48-B read per lane, so a
+// leaf of k primitives is k*48 contiguous bytes.
+//   triangle: q0 = (v0.x, v0.y, v0.z, bits(prim_id))
+//             q1 = (e1.x, e1.y, e1.z, bits(0))      e1 = v1 - v0
+//             q2 = (e2.x, e2.y, e2.z, 0)            e2 = v2 - v0
+//   sphere:   q0 = (c.x,  c.y,  c.z,  bits(prim_id))
+//             q1 = (r, 0, 0, bits(1))
+// In BVH mode records are stored in Morton order (leaf ranges are contiguous);
+// in exhaustive mode in primitive-id order.
+//
+// BvhNode (64 B, four quads): one traversal step fetches both children's boxes.
+//   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)
+//   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
+//   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)
+//   q3 = (bits(left), bits(right), 0, 0)
+// child >= 0: index of another BvhNode; child < 0: ~child = (first << 3) | (count - 1),
+// a leaf of `count` (1..8) consecutive PrimRecs starting at `first`.
+// ---------------------------------------------------------------------------
+struct PrimRec {
+    float4 q0, q1, q2;
+};
+struct BvhNode {
+    float4 q0, q1, q2, q3;
+};
+static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+#define RTX_LEAF_MAX 4          // primitives per collapsed leaf (<= 8)
+#define RTX_EXHAUSTIVE_MAX 16   // scenes with at most this many primitives skip the BVH
+#define RTX_TILE 8              // primary rays are generated in 8x8-pixel tiles (one wavefront)
+
+struct DevLight {  // 48 B
+    float a[3];
+    uint32_t type;
+    float b[3];
+    float pad0;
+    float color[3];
+    float pad1;
+};
+
+// Everything a kernel needs to know about the scene; passed by value.
+struct DevScene {
+    uint32_t n_prims, n_tris, n_spheres, n_lights, n_materials;
+    uint32_t uses_bvh;
+    uint32_t has_transparent;   // some material has transparency != 0
+    uint32_t has_area_light;
+    // shading-side arrays, indexed through prim_ref by reference primitive id
+    const uint32_t* prim_ref;   // [n_prims] bit 31 set = sphere; low 31 bits = index into its type's arrays
+    const float* tri_pos;       // [n_tris][9]
+    const float* tri_nrm;       // [n_tris][9] or nullptr
+    const uint32_t* tri_mat;    // [n_tris][3]
+    const uint8_t* tri_flags;   // [n_tris]
+    const float4* sph;          // [n_spheres] (c.xyz, r)
+    const uint32_t* sph_mat;    // [n_spheres]
+    const rtx_material* mats;   // [n_materials]
+    const DevLight* lights;     // [n_lights]
+    // traversal-side arrays
+    const PrimRec* recs;        // [n_prims]
+    const BvhNode* nodes;       // [n_prims - 1] (sparse: only non-collapsed nodes are valid)
+    // Rays whose origin lies outside the cube |o - safe_c|_inf <= safe_r take the
+    // exhaustive loop: the sphere padding of the BVH is only proven inside it.
+    float safe_c[3];
+    float safe_r;
+    float pad_rel;              // relative padding constant of the box test
+};
+
+// Work queue of rays: three arrays of 16-/8-byte elements so that every access
+// of a wavefront is one fully coalesced 1 KiB (or 512 B) transaction.
+//   o[i]   = (origin.xyz, bits(link))   link: level 0 = pixel slot; deeper = parent pool slot | (branch << 31)
+//   d[i]   = (dir.xyz,    bits(flags))  flags bit0: ray is in vacuum (src/ray.rs:9); bit1: ray is valid
+//   hit[i] = (prim_id, bits(t))         written by the traversal kernel
+struct RayQueue {
+    float4* o;
+    float4* d;
+    uint2* hit;
+};
+#define RTX_RAY_VACUUM 1u
+#define RTX_RAY_VALID 2u
+
+struct rtx_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    bool has_scene = false, built = false;
+
+    // host copies of small things
+    rtx_camera camera{};
+    std::vector<rtx_light> lights;
+    DevScene ds{};
+    rtx_build_stats build_stats{};
+    float scene_min[3]{}, scene_max[3]{};
+
+    // owned device allocations for the scene
+    std::vector<void*> scene_allocs;
+    std::vector<void*> build_allocs;
+    // render workspace (grown on demand)
+    std::vector<void*> work_allocs;
+    uint64_t work_batch = 0;      // pixels per batch the workspace was sized for
+    uint32_t work_lights = 0;
+
+    std::vector<char> work_blob;  // the Work struct of rtx_shade.hip describing work_allocs
+    std::vector<hipEvent_t> events;
+    bool has_secondary = false;   // some material reflects or refracts (src/lib.rs:230,241)
+
+    // knobs (rtx_set_option)
+    int64_t opt_force_mode = 0;   // 0 auto, 1 exhaustive, 2 bvh
+    int64_t opt_batch_pixels = 1 << 22;
+    int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
+    int64_t opt_profile = 0;      // time traversal kernels separately (adds events)
+};
+
+// -- helpers shared by the translation units ---------------------------------
+int rtx_fail(rtx_context* ctx, int status, const std::string& msg);
+#define RTX_HIP(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return rtx_fail((ctx), RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// rtx_bvh.hip
+int rtx_bvh_build(rtx_context* ctx);
+// rtx_trace.hip
+int rtx_stack_for(uint32_t depth_needed);
+int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                         int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);
+// rtx_shade.hip
+int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
+                    uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats);
+int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir);
+int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb);

@@ -1,0 +1,675 @@
+// rtx_shade.hip -- the frame: RayTracer::trace_rays (src/lib.rs:257-277) and the
+// Whitted recursion shade_intersection (src/lib.rs:201-255) flattened into
+// bounded-depth ray queues.
+//
+// Color clamps on every operation (src/scene/material.rs:17-27,65-84), so a
+// node's colour needs its children's FINAL colours: throughput-weighted
+// accumulation is not equivalent. The recursion therefore becomes
+//   forward, level 0..D-1 : trace queue -> shade_a (hit geometry, node alloc)
+//                           -> shadow rays (one task per node and light)
+//                           -> shade_b (lights summed in scene order, children spawned)
+//   backward, level D-1..0: combine ((direct+ambient) + ks*refl) + refr*kt, each
+//                           child writing its final colour into its parent's slot.
+// Every count lives in device memory (Ctl); the host only reads the size of the
+// next queue once per level to stop early.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <utility>
+
+#include "rtx_shading.h"
+#include "rtx_traverse.h"
+
+int rtx_stack_for(uint32_t depth_needed);
+
+namespace {
+
+struct Ctl {
+    uint32_t n_rays[2];
+    uint32_t n_nodes;
+    uint32_t pool_base;
+    uint32_t overflow;
+    uint32_t pad[3];
+    uint32_t level_start[RTX_MAX_DEPTH + 2];
+    unsigned long long stat[7];    // primary, shadow, reflect, refract, skipped, nodes, panic
+    unsigned long long saved[7];   // snapshot at batch start, restored when a batch is re-rendered
+};
+enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_REFRACT, ST_SKIPPED, ST_NODES, ST_PANIC };
+
+struct Work {
+    RayQueue q[2];
+    uint32_t cap_rays;
+    float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir, pool slot) (cd, -)
+    float* shadow;               // [n_lights][cap_rays] shadow scalars
+    float4 *pL, *pC0, *pC1;      // retained pool: (local colour, mat0), reflected child colour, refracted child colour
+    uint32_t* pLink;             // retained pool: parent link
+    uint32_t cap_pool;
+    Ctl* ctl;
+};
+
+struct CamSetup {   // RayTracer fields after setup_camera (lib.rs:69-84) plus the two plane vectors (lib.rs:86-94)
+    V3 center, cam_pos, hplane, vplane;
+    float inv_w, inv_h;
+    uint32_t w, h;
+};
+
+CamSetup make_cam(const rtx_camera& c, uint32_t w, uint32_t h) {
+    const float SCALE = 10000.0f;  // lib.rs:22
+    CamSetup cs;
+    const V3 view = v3(c.view_dir[0], c.view_dir[1], c.view_dir[2]);
+    const V3 up = v3(c.ortho_up[0], c.ortho_up[1], c.ortho_up[2]);
+    const V3 pos = v3(c.pos[0], c.pos[1], c.pos[2]);
+    V3 right = vcross(view, up);
+    V3 pup = vcross(right, view);
+    right = vnormalize(right);
+    pup = vnormalize(pup);
+    const float vfov = c.vertical_fov;
+    const float hfov = c.vertical_fov * ((float)w / (float)h);
+    cs.cam_pos = pos;
+    cs.center = pos + vmult(view, SCALE);
+    cs.vplane = vmult(pup, tanf(vfov / 2.0f) * SCALE);
+    cs.hplane = vmult(right, tanf(hfov / 2.0f) * SCALE);
+    cs.inv_w = 1.0f / (float)w;
+    cs.inv_h = 1.0f / (float)h;
+    cs.w = w;
+    cs.h = h;
+    return cs;
+}
+
+// RayTracer::compute_ray (lib.rs:96-103); the missing `- camera_pos` is the reference's behaviour.
+RTX_D V3 compute_ray_dir(const CamSetup& c, float x, float y) {
+    x = x * c.inv_w;
+    y = y * c.inv_h;
+    const V3 dx = vmult(c.hplane, 2.0f * x - 1.0f);
+    const V3 dy = vmult(c.vplane, 2.0f * y - 1.0f);
+    return vnormalize(c.center + dx + dy);
+}
+
+RTX_D uint64_t lanemask_lt() {
+    const int lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+// Wave-aggregated allocation: one atomic per wavefront. Must be called by all lanes of the wave.
+RTX_D uint32_t wave_alloc(uint32_t* counter, bool want, uint32_t count_each = 1) {
+    const uint64_t m = __ballot(want);
+    if (m == 0) return 0;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (uint32_t)__popcll(m) * count_each);
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & lanemask_lt()) * count_each;
+}
+RTX_D void wave_count(unsigned long long* counter, bool flag) {
+    const uint64_t m = __ballot(flag);
+    if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
+    for (int k = 0; k < 7; ++k) {
+        if (rollback) ctl->stat[k] = ctl->saved[k];
+        else ctl->saved[k] = ctl->stat[k];
+    }
+    ctl->overflow = 0;
+    ctl->n_rays[0] = n;
+    ctl->n_rays[1] = 0;
+    ctl->n_nodes = 0;
+    ctl->pool_base = 0;
+    ctl->level_start[0] = 0;
+}
+
+// Primary rays of one batch. Ray g of a rank lives in tile (g / 64) of that rank's
+// interleaved tile list and is pixel (g % 8, g / 8 % 8) of the tile: one
+// wavefront = one 8x8-pixel tile, so its 64 rays are coherent.
+__global__ __launch_bounds__(RTX_BLOCK) void k_raygen(CamSetup cam, Work wk, uint64_t first, uint32_t n, uint32_t rank,
+                                                      uint32_t world, uint32_t tiles_x, uint32_t n_tiles) {
+    const uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    bool valid = false;
+    if (i < n) {
+        const uint64_t g = first + i;
+        const uint64_t tile = (g >> 6) * world + rank;
+        const uint32_t lane = (uint32_t)(g & 63);
+        const uint32_t x = (uint32_t)(tile % tiles_x) * RTX_TILE + (lane & 7u);
+        const uint32_t y = (uint32_t)(tile / tiles_x) * RTX_TILE + (lane >> 3);
+        valid = tile < n_tiles && x < cam.w && y < cam.h;
+        V3 d = v3(0.0f, 0.0f, 0.0f);
+        if (valid) d = compute_ray_dir(cam, (float)x, (float)(cam.h - y - 1));   // lib.rs:263
+        wk.q[0].o[i] = make_float4(cam.cam_pos.x, cam.cam_pos.y, cam.cam_pos.z, u2f((uint32_t)g));
+        wk.q[0].d[i] = make_float4(d.x, d.y, d.z, u2f(valid ? (RTX_RAY_VALID | RTX_RAY_VACUUM) : 0u));
+    }
+    wave_count(&wk.ctl->stat[ST_PRIMARY], valid);
+}
+
+// Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201).
+template <int STACK>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue q, const uint32_t* __restrict__ n_ptr,
+                                                           const uint32_t* __restrict__ overflow) {
+    __shared__ int lds[STACK * RTX_BLOCK];
+    LaneStack<STACK> st;
+    st.set(lds);
+    if (*overflow) return;   // the batch is being abandoned
+    const uint32_t n = *n_ptr;
+    for (uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += gridDim.x * RTX_BLOCK) {
+        const float4 o4 = q.o[i], d4 = q.d[i];
+        int id = -1;
+        float t = 0.0f;
+        if (f2u(d4.w) & RTX_RAY_VALID) trace_closest<STACK>(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
+        q.hit[i] = make_uint2((uint32_t)id, f2u(t));
+    }
+}
+
+// Forward step 1: every hit becomes a shading node (shade_intersection is only
+// entered for hits: lib.rs:264-271, 232-236, 243-247).
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi) {
+    Ctl* ctl = wk.ctl;
+    if (ctl->overflow) return;
+    const uint32_t n = ctl->n_rays[qi];
+    const uint32_t pool_base = ctl->pool_base;
+    const RayQueue q = wk.q[qi];
+    const uint32_t stride = gridDim.x * RTX_BLOCK;
+    for (uint32_t base = blockIdx.x * RTX_BLOCK; base < n; base += stride) {   // wave-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        bool want = false;
+        uint2 hit = make_uint2(0xffffffffu, 0u);
+        if (i < n) {
+            hit = q.hit[i];
+            want = (int)hit.x >= 0;
+        }
+        uint32_t node = wave_alloc(&ctl->n_nodes, want);
+        if (want && (node >= wk.cap_rays || pool_base + node >= wk.cap_pool)) {
+            ctl->overflow = 1;
+            want = false;
+        }
+        bool panic = false;
+        if (want) {
+            const float4 o4 = q.o[i], d4 = q.d[i];
+            const V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
+            const HitGeom g = hit_geometry(s, (int)hit.x, o, d, u2f(hit.y), true);
+            panic = g.panic;
+            const uint32_t slot = pool_base + node;
+            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (panic ? 4u : 0u);
+            wk.nP[node] = make_float4(g.p.x, g.p.y, g.p.z, u2f(g.mat0));
+            wk.nN[node] = make_float4(g.n.x, g.n.y, g.n.z, u2f(nflags));
+            wk.nV[node] = make_float4(d.x, d.y, d.z, u2f(slot));
+            wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);
+            wk.pLink[slot] = f2u(o4.w);
+        }
+        wave_count(&ctl->stat[ST_NODES], want);
+        wave_count(&ctl->stat[ST_PANIC], panic);
+    }
+}
+
+// Forward step 2: RayTracer::shadow_scalar (lib.rs:105-141) for one (node, light)
+// per lane, tasks ordered light-major so a wavefront's rays converge on one light.
+// ANY: scenes without transparent materials, first occluder ends the search.
+// otherwise: closest hit, continued through transparent hits up to `depth` times;
+// the chain's transparencies are parked in the top of the lane's LDS stack so the
+// products can be formed innermost-first exactly as the recursion does.
+template <int STACK, bool ANY>
+__global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint32_t depth) {
+    __shared__ int lds[STACK * RTX_BLOCK];
+    LaneStack<STACK> st;
+    st.set(lds);
+    Ctl* ctl = wk.ctl;
+    if (ctl->overflow) return;
+    const uint32_t nn = ctl->n_nodes;
+    const uint64_t total = (uint64_t)nn * s.n_lights;
+    const uint64_t stride = (uint64_t)gridDim.x * RTX_BLOCK;
+    unsigned long long rays = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * RTX_BLOCK; base < total; base += stride) {
+        const uint64_t k = base + threadIdx.x;
+        if (k < total) {
+            const uint32_t j = (uint32_t)(k / nn), node = (uint32_t)(k - (uint64_t)j * nn);
+            const DevLight light = s.lights[j];
+            const float4 p4 = wk.nP[node], n4 = wk.nN[node];
+            const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z);
+            float result = 0.0f;
+            const float fattj = calculate_fattj(light, point);   // lights with fattj <= 0 are skipped (lib.rs:218)
+            if (fattj > 0.0f) {
+                V3 ori = point + vmult(normal, 0.0001f);          // lib.rs:111
+                V3 dir = light_dir(light, ori);
+                const bool directional = light.type == RTX_LIGHT_DIRECTIONAL;
+                if (ANY) {
+                    const float dl = directional ? -1.0f : vdistance(ori, light_pos(light));
+                    ++rays;
+                    const float term = trace_any<STACK>(s, ori, dir, dl, st) ? 0.0f : 1.0f;
+                    result = clamp01((0.0f + term) / 1.0f);
+                } else {
+                    int chain = 0;
+                    uint32_t rem = depth;
+                    float inner;   // value returned by the innermost shadow_scalar call
+                    for (;;) {
+                        ++rays;
+                        float t;
+                        int id;
+                        trace_closest<STACK>(s, ori, dir, st, t, id);
+                        float term;
+                        if (id < 0) {
+                            term = 1.0f;
+                        } else {
+                            const HitGeom g = hit_geometry(s, id, ori, dir, t, false);
+                            const rtx_material* m = material_or_null(s, g.mat0);
+                            const float kt = m ? m->transparency : 0.0f;
+                            if (kt == 0.0f) {
+                                term = directional ? 0.0f
+                                                   : ((vdistance(ori, g.p) > vdistance(ori, light_pos(light))) ? 1.0f : 0.0f);
+                            } else {
+                                // kt * shadow_scalar(hit, depth - 1)
+                                st.put(STACK - 1 - chain, (int)f2u(kt));
+                                ++chain;
+                                --rem;
+                                if (rem == 0) { inner = 0.0f; break; }   // depth <= 0 -> Color::new()
+                                ori = g.p + vmult(g.n, 0.0001f);
+                                dir = light_dir(light, ori);
+                                continue;
+                            }
+                        }
+                        inner = clamp01((0.0f + term) / 1.0f);
+                        break;
+                    }
+                    while (chain > 0) {
+                        --chain;
+                        const float kt = u2f((uint32_t)st.get(STACK - 1 - chain));
+                        inner = clamp01((0.0f + kt * inner) / 1.0f);
+                    }
+                    result = inner;
+                }
+            }
+            wk.shadow[(size_t)j * wk.cap_rays + node] = result;
+        }
+    }
+    // one atomic per wavefront
+    for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
+}
+
+// Forward step 3: local colour and children.
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth) {
+    Ctl* ctl = wk.ctl;
+    if (ctl->overflow) return;
+    const uint32_t nn = ctl->n_nodes;
+    const RayQueue q = wk.q[qo];
+    const uint32_t stride = gridDim.x * RTX_BLOCK;
+    const bool spawn = node_depth > 1;   // children are shaded at node_depth - 1
+    for (uint32_t base = blockIdx.x * RTX_BLOCK; base < nn; base += stride) {
+        const uint32_t node = base + threadIdx.x;
+        bool refl = false, refr = false;
+        V3 ro0, rd0, ro1, rd1;
+        uint32_t slot = 0;
+        if (node < nn) {
+            const float4 p4 = wk.nP[node], n4 = wk.nN[node], v4 = wk.nV[node], c4 = wk.nC[node];
+            const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z), dir = v3(v4.x, v4.y, v4.z);
+            const Col cd = Col{c4.x, c4.y, c4.z};
+            const uint32_t mat0 = f2u(p4.w), nflags = f2u(n4.w);
+            slot = f2u(v4.w);
+            const rtx_material* m = material_or_null(s, mat0);
+            const float kt = m ? m->transparency : 0.0f;
+            const float shininess = m ? m->shininess : 0.0f;
+            const Col ks = m ? col_raw(m->specular) : col_new();
+            const Col ka = m ? col_raw(m->ambient) : col_new();
+            const Col ambient_light = col_mult(cd * ka, 1.0f - kt);   // lib.rs:143-145
+            Col direct_light = col_new();
+            for (uint32_t j = 0; j < s.n_lights; ++j) {              // lib.rs:216-228, scene order
+                const DevLight light = s.lights[j];
+                const float fattj = calculate_fattj(light, point);
+                if (fattj > 0.0f) {
+                    const float ss = wk.shadow[(size_t)j * wk.cap_rays + node];
+                    direct_light = direct_light + direct_lightning(light, point, normal, dir, cd, ks, kt, shininess,
+                                                                   Col{ss, ss, ss}, fattj);
+                }
+            }
+            const Col local = direct_light + ambient_light;           // first '+' of lib.rs:254
+            wk.pL[slot] = make_float4(local.r, local.g, local.b, u2f(mat0));
+            wk.pC0[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            wk.pC1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col_scalar(ks) > 0.0f) {                              // lib.rs:230
+                refl = true;
+                reflective_ray(dir, point, normal, ro0, rd0);
+            }
+            if (kt > 0.0f) refr = refractive_ray(dir, point, normal, (nflags & RTX_RAY_VACUUM) != 0, ro1, rd1);   // lib.rs:241-242
+        }
+        wave_count(&ctl->stat[ST_REFLECT], refl);
+        wave_count(&ctl->stat[ST_REFRACT], refr);
+        if (!spawn) {   // wave-uniform
+            wave_count(&ctl->stat[ST_SKIPPED], refl);
+            wave_count(&ctl->stat[ST_SKIPPED], refr);
+            continue;
+        }
+        uint32_t i0 = wave_alloc(&ctl->n_rays[qo], refl);
+        if (refl && i0 >= wk.cap_rays) { ctl->overflow = 1; refl = false; }
+        if (refl) {
+            q.o[i0] = make_float4(ro0.x, ro0.y, ro0.z, u2f(slot));
+            q.d[i0] = make_float4(rd0.x, rd0.y, rd0.z, u2f(RTX_RAY_VALID | RTX_RAY_VACUUM));
+        }
+        uint32_t i1 = wave_alloc(&ctl->n_rays[qo], refr);
+        if (refr && i1 >= wk.cap_rays) { ctl->overflow = 1; refr = false; }
+        if (refr) {   // refracted rays are never "in vacuum" again (intersection.rs:77-78)
+            q.o[i1] = make_float4(ro1.x, ro1.y, ro1.z, u2f(slot | 0x80000000u));
+            q.d[i1] = make_float4(rd1.x, rd1.y, rd1.z, u2f(RTX_RAY_VALID));
+        }
+    }
+}
+
+__global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t cap_rays) {
+    ctl->pool_base += min(ctl->n_nodes, cap_rays);
+    ctl->level_start[level + 1] = ctl->pool_base;
+    ctl->n_nodes = 0;
+    ctl->n_rays[q_consumed] = 0;
+    if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
+}
+
+// Backward: `direct + ambient + reflective + refractive` (lib.rs:254) with
+// reflective = ks * child (lib.rs:234) and refractive = child.mult(kt) (lib.rs:244-245).
+// A missing child left its slot at zero, which yields the same value as Color::new().
+__global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint32_t level, uint8_t* __restrict__ rgb) {
+    const Ctl* ctl = wk.ctl;
+    if (ctl->overflow) return;
+    const uint32_t lo = ctl->level_start[level], hi = ctl->level_start[level + 1];
+    for (uint32_t slot = lo + blockIdx.x * RTX_BLOCK + threadIdx.x; slot < hi; slot += gridDim.x * RTX_BLOCK) {
+        const float4 l4 = wk.pL[slot], c0 = wk.pC0[slot], c1 = wk.pC1[slot];
+        const rtx_material* m = material_or_null(s, f2u(l4.w));
+        const Col ks = m ? col_raw(m->specular) : col_new();
+        const float kt = m ? m->transparency : 0.0f;
+        const Col reflective = ks * Col{c0.x, c0.y, c0.z};
+        const Col refractive = col_mult(Col{c1.x, c1.y, c1.z}, kt);
+        const Col c = (Col{l4.x, l4.y, l4.z} + reflective) + refractive;
+        const uint32_t link = wk.pLink[slot];
+        if (level == 0) {
+            uint8_t* px = rgb + (size_t)link * 3;   // Color::as_pixel, material.rs:57-63
+            px[0] = col_u8(c.r);
+            px[1] = col_u8(c.g);
+            px[2] = col_u8(c.b);
+        } else {
+            const uint32_t parent = link & 0x7fffffffu;
+            float4* dst = (link >> 31) ? wk.pC1 : wk.pC0;
+            dst[parent] = make_float4(c.r, c.g, c.b, 0.0f);
+        }
+    }
+}
+
+// Gathered slabs [world][tiles_per_rank][64][3] -> row-major image.
+__global__ __launch_bounds__(RTX_BLOCK) void k_assemble(uint32_t w, uint32_t h, uint32_t world, uint32_t tiles_x,
+                                                        uint64_t tiles_per_rank, const uint8_t* __restrict__ slabs,
+                                                        uint8_t* __restrict__ rgb) {
+    const uint64_t npix = (uint64_t)w * h;
+    for (uint64_t p = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x; p < npix; p += (uint64_t)gridDim.x * RTX_BLOCK) {
+        const uint32_t x = (uint32_t)(p % w), y = (uint32_t)(p / w);
+        const uint64_t tile = (uint64_t)(y / RTX_TILE) * tiles_x + x / RTX_TILE;
+        const uint64_t src = ((tile % world) * tiles_per_rank + tile / world) * 64 + (y % RTX_TILE) * 8 + x % RTX_TILE;
+        rgb[p * 3 + 0] = slabs[src * 3 + 0];
+        rgb[p * 3 + 1] = slabs[src * 3 + 1];
+        rgb[p * 3 + 2] = slabs[src * 3 + 2];
+    }
+}
+
+__global__ __launch_bounds__(RTX_BLOCK) void k_primary_out(RayQueue q, uint64_t first, uint32_t n, uint32_t w, uint32_t h,
+                                                           uint32_t tiles_x, int32_t* __restrict__ prim,
+                                                           float* __restrict__ t, float* __restrict__ dir) {
+    const uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 d4 = q.d[i];
+    if (!(f2u(d4.w) & RTX_RAY_VALID)) return;
+    const uint32_t tile = (uint32_t)((first + i) >> 6), lane = (uint32_t)((first + i) & 63);
+    const uint32_t x = (tile % tiles_x) * RTX_TILE + (lane & 7u), y = (tile / tiles_x) * RTX_TILE + (lane >> 3);
+    const size_t p = (size_t)y * w + x;
+    const uint2 hit = q.hit[i];
+    if (prim) prim[p] = (int)hit.x;
+    if (t) t[p] = ((int)hit.x >= 0) ? u2f(hit.y) : 0.0f;
+    if (dir) { dir[p * 3] = d4.x; dir[p * 3 + 1] = d4.y; dir[p * 3 + 2] = d4.z; }
+}
+
+template <typename T>
+int walloc(rtx_context* ctx, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+    ctx->work_allocs.push_back(p);
+    *out = (T*)p;
+    return RTX_OK;
+}
+
+int ensure_workspace(rtx_context* ctx, uint64_t batch, Work* out) {
+    static_assert(sizeof(Work) < 512, "Work is passed by value");
+    const uint32_t lights = std::max<uint32_t>(ctx->ds.n_lights, 1);
+    if (ctx->work_batch >= batch && ctx->work_lights >= lights && ctx->work_blob.size() == sizeof(Work)) {
+        std::memcpy(out, ctx->work_blob.data(), sizeof(Work));
+        return RTX_OK;
+    }
+    for (void* p : ctx->work_allocs) (void)hipFree(p);
+    ctx->work_allocs.clear();
+    ctx->work_batch = 0;
+    Work wk{};
+    const uint64_t cap_rays64 = std::min<uint64_t>(2 * batch, 0x7fffffffull);
+    const uint64_t cap_pool64 = std::min<uint64_t>((uint64_t)ctx->opt_pool_factor * batch, 0x7fffffffull);
+    wk.cap_rays = (uint32_t)cap_rays64;
+    wk.cap_pool = (uint32_t)cap_pool64;
+#define W_TRY(x) do { int rc_ = (x); if (rc_ != RTX_OK) return rc_; } while (0)
+    for (int k = 0; k < 2; ++k) {
+        W_TRY(walloc(ctx, &wk.q[k].o, wk.cap_rays));
+        W_TRY(walloc(ctx, &wk.q[k].d, wk.cap_rays));
+        W_TRY(walloc(ctx, &wk.q[k].hit, wk.cap_rays));
+    }
+    W_TRY(walloc(ctx, &wk.nP, wk.cap_rays));
+    W_TRY(walloc(ctx, &wk.nN, wk.cap_rays));
+    W_TRY(walloc(ctx, &wk.nV, wk.cap_rays));
+    W_TRY(walloc(ctx, &wk.nC, wk.cap_rays));
+    W_TRY(walloc(ctx, &wk.shadow, (size_t)wk.cap_rays * lights));
+    W_TRY(walloc(ctx, &wk.pL, wk.cap_pool));
+    W_TRY(walloc(ctx, &wk.pC0, wk.cap_pool));
+    W_TRY(walloc(ctx, &wk.pC1, wk.cap_pool));
+    W_TRY(walloc(ctx, &wk.pLink, wk.cap_pool));
+    W_TRY(walloc(ctx, &wk.ctl, 1));
+#undef W_TRY
+    ctx->work_batch = batch;
+    ctx->work_lights = lights;
+    ctx->work_blob.assign((const char*)&wk, (const char*)&wk + sizeof(Work));
+    *out = wk;
+    return RTX_OK;
+}
+
+inline uint32_t blocks_for(uint64_t n, uint32_t cap) {
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + RTX_BLOCK - 1) / RTX_BLOCK, cap));
+}
+
+struct EventPool {
+    rtx_context* ctx;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == ctx->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ctx->events.push_back(e);
+        }
+        return (hipEvent_t)ctx->events[used++];
+    }
+};
+
+template <int STACK>
+void launch_trace(const DevScene& s, const RayQueue& q, const uint32_t* n_ptr, const uint32_t* overflow, uint32_t n_upper,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(k_trace_queue<STACK>, dim3(blocks_for(n_upper, 1u << 20)), dim3(RTX_BLOCK), 0, st, s, q, n_ptr, overflow);
+}
+void dispatch_trace(int stack, const DevScene& s, const RayQueue& q, const uint32_t* n_ptr, const uint32_t* overflow,
+                    uint32_t n_upper, hipStream_t st) {
+    if (stack == 32) launch_trace<32>(s, q, n_ptr, overflow, n_upper, st);
+    else if (stack == 64) launch_trace<64>(s, q, n_ptr, overflow, n_upper, st);
+    else launch_trace<128>(s, q, n_ptr, overflow, n_upper, st);
+}
+template <int STACK>
+void launch_shadow(const DevScene& s, const Work& wk, uint32_t depth, uint64_t tasks_upper, bool any, hipStream_t st) {
+    const dim3 grid(blocks_for(tasks_upper, 1u << 20));
+    if (any) hipLaunchKernelGGL((k_shadow<STACK, true>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+    else hipLaunchKernelGGL((k_shadow<STACK, false>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+}
+
+}  // namespace
+
+uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
+    if (world == 0) return 0;
+    const uint64_t tiles = (uint64_t)((width + RTX_TILE - 1) / RTX_TILE) * ((height + RTX_TILE - 1) / RTX_TILE);
+    return (tiles + world - 1) / world;
+}
+
+int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
+                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats) {
+    (void)samples;   // num_samples only multiplies area-light rays (lib.rs:219-222)
+    const DevScene& s = ctx->ds;
+    hipStream_t st = ctx->stream;
+    if (depth > RTX_MAX_DEPTH) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "depth above RTX_MAX_DEPTH");
+    if (s.has_area_light) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "area lights are not implemented on the device yet");
+    const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE, tiles_y = (h + RTX_TILE - 1) / RTX_TILE;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    if (n_tiles >= (1ull << 25)) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "image too large");
+    const uint64_t tiles_per_rank = rtx_tiles_per_rank(w, h, world);
+    const uint64_t tiles_local = (rank < n_tiles) ? (n_tiles - rank + world - 1) / world : 0;
+    const uint64_t rays_local = tiles_local * 64;
+    RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, tiles_per_rank * 64 * 3, st));
+
+    uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays_local, 64));
+    batch = (batch + 63) & ~63ull;
+    Work wk;
+    int rc = ensure_workspace(ctx, batch, &wk);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
+
+    const CamSetup cam = make_cam(ctx->camera, w, h);
+    // Without reflective or refractive materials no child is ever spawned: one level is exact.
+    const uint32_t levels = ctx->has_secondary ? depth : std::min<uint32_t>(depth, 1);
+    const bool any_shadow = !s.has_transparent;
+    const int stack_trace = rtx_stack_for(ctx->build_stats.max_depth + 1);
+    const int stack_shadow = rtx_stack_for(ctx->build_stats.max_depth + 1 + (any_shadow ? 0 : depth));
+
+    EventPool ev{ctx};
+    hipEvent_t f0 = ev.next(), f1 = ev.next();
+    if (!f0 || !f1) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    RTX_HIP(ctx, hipEventRecord(f0, st));
+    uint32_t n_batches = 0;
+    uint64_t cur_batch = batch;
+    int rollback = 0;
+    for (uint64_t first = 0; first < rays_local;) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(cur_batch, rays_local - first);
+        ++n_batches;
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback);
+        rollback = 0;
+        hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, cam, wk, first, n, rank, world,
+                           tiles_x, (uint32_t)n_tiles);
+        int qi = 0;
+        uint32_t n_rays = n, levels_done = 0;
+        if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
+            dispatch_trace(stack_trace, s, wk.q[0], &wk.ctl->n_rays[0], &wk.ctl->overflow, n_rays, st);
+        for (uint32_t level = 0; level < levels; ++level) {
+            hipEvent_t a = ev.next(), b = ev.next();
+            if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+            RTX_HIP(ctx, hipEventRecord(a, st));
+            dispatch_trace(stack_trace, s, wk.q[qi], &wk.ctl->n_rays[qi], &wk.ctl->overflow, n_rays, st);
+            RTX_HIP(ctx, hipEventRecord(b, st));
+            trace_events.emplace_back(a, b);
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
+            if (s.n_lights > 0) {
+                hipEvent_t c = ev.next(), d = ev.next();
+                if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+                RTX_HIP(ctx, hipEventRecord(c, st));
+                const uint64_t tasks = (uint64_t)n_rays * s.n_lights;
+                if (stack_shadow == 32) launch_shadow<32>(s, wk, depth - level, tasks, any_shadow, st);
+                else if (stack_shadow == 64) launch_shadow<64>(s, wk, depth - level, tasks, any_shadow, st);
+                else launch_shadow<128>(s, wk, depth - level, tasks, any_shadow, st);
+                RTX_HIP(ctx, hipEventRecord(d, st));
+                trace_events.emplace_back(c, d);
+            }
+            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level);
+            hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
+            levels_done = level + 1;
+            if (level + 1 < levels) {
+                uint32_t next = 0;
+                RTX_HIP(ctx, hipMemcpyAsync(&next, &wk.ctl->n_rays[qi ^ 1], 4, hipMemcpyDeviceToHost, st));
+                RTX_HIP(ctx, hipStreamSynchronize(st));
+                if (next == 0) break;
+                n_rays = std::min(next, wk.cap_rays);
+                qi ^= 1;
+            }
+        }
+        for (uint32_t level = levels_done; level-- > 0;) {
+            const uint64_t upper = (level == 0) ? n : wk.cap_rays;
+            hipLaunchKernelGGL(k_combine, dim3(blocks_for(upper, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, level, d_rgb_tiles);
+        }
+        uint32_t overflow = 0;
+        RTX_HIP(ctx, hipMemcpyAsync(&overflow, &wk.ctl->overflow, 4, hipMemcpyDeviceToHost, st));
+        RTX_HIP(ctx, hipStreamSynchronize(st));
+        if (overflow) {
+            // The ray tree of this batch outgrew the queues: render the same pixels again in
+            // smaller batches (the workspace keeps its size, so relative capacity doubles).
+            if (cur_batch <= 64)
+                return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "ray queues overflow even for one tile; raise the pool_factor option");
+            cur_batch = std::max<uint64_t>(64, (cur_batch / 2 + 63) & ~63ull);
+            rollback = 1;   // k_batch_init restores the ray counters of the abandoned attempt
+            continue;
+        }
+        first += n;
+    }
+    RTX_HIP(ctx, hipEventRecord(f1, st));
+    RTX_HIP(ctx, hipEventSynchronize(f1));
+    RTX_HIP(ctx, hipGetLastError());
+    if (stats) {
+        Ctl hc;
+        RTX_HIP(ctx, hipMemcpy(&hc, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+        rtx_render_stats rs{};
+        rs.primary_rays = hc.stat[ST_PRIMARY];
+        rs.shadow_rays = hc.stat[ST_SHADOW];
+        rs.reflect_rays = hc.stat[ST_REFLECT];
+        rs.refract_rays = hc.stat[ST_REFRACT];
+        rs.skipped_rays = hc.stat[ST_SKIPPED];
+        rs.shaded_nodes = hc.stat[ST_NODES];
+        rs.panic_pixels = hc.stat[ST_PANIC];
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, f0, f1);
+        rs.render_ms = ms;
+        float tsum = 0.0f;
+        for (auto& p : trace_events) {
+            float e = 0.0f;
+            (void)hipEventElapsedTime(&e, p.first, p.second);
+            tsum += e;
+        }
+        rs.trace_ms = tsum;
+        rs.trace_launches = (uint32_t)trace_events.size();
+        rs.batches = n_batches;
+        *stats = rs;
+    }
+    return RTX_OK;
+}
+
+int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir) {
+    const DevScene& s = ctx->ds;
+    hipStream_t st = ctx->stream;
+    const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE, tiles_y = (h + RTX_TILE - 1) / RTX_TILE;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    if (n_tiles >= (1ull << 25)) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "image too large");
+    const uint64_t rays = n_tiles * 64;
+    uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays, 64));
+    batch = (batch + 63) & ~63ull;
+    Work wk;
+    int rc = ensure_workspace(ctx, batch, &wk);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
+    const CamSetup cam = make_cam(ctx->camera, w, h);
+    const int stack = rtx_stack_for(ctx->build_stats.max_depth + 1);
+    for (uint64_t first = 0; first < rays; first += batch) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(batch, rays - first);
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0);
+        hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, cam, wk, first, n, 0u, 1u, tiles_x,
+                           (uint32_t)n_tiles);
+        dispatch_trace(stack, s, wk.q[0], &wk.ctl->n_rays[0], &wk.ctl->overflow, n, st);
+        hipLaunchKernelGGL(k_primary_out, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, wk.q[0], first, n, w, h, tiles_x,
+                           d_prim, d_t, d_dir);
+    }
+    RTX_HIP(ctx, hipStreamSynchronize(st));
+    RTX_HIP(ctx, hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb) {
+    const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE;
+    hipLaunchKernelGGL(k_assemble, dim3(blocks_for((uint64_t)w * h, 8192)), dim3(RTX_BLOCK), 0, ctx->stream, w, h, world, tiles_x,
+                       rtx_tiles_per_rank(w, h, world), d_slabs, d_rgb);
+    RTX_HIP(ctx, hipGetLastError());
+    return RTX_OK;
+}

@@ -1,0 +1,143 @@
+// rtx_shading.h -- per-hit geometry, secondary rays and the local lighting terms.
+// Every function restates the cited reference function with the same operation
+// order; the recursion of src/lib.rs:201-255 itself is flattened by the kernels
+// in rtx_shade.hip.
+#pragma once
+#include "rtx_internal.h"
+
+struct HitGeom {
+    V3 p;           // Intersection::point            (intersection.rs:26-28)
+    V3 n;           // Intersection::surface_normal   (intersection.rs:38-40)
+    Col cd;         // Intersection::color            (intersection.rs:30-32)
+    uint32_t mat0;  // Intersection::material = materials[0] (poly.rs:181-183, sphere.rs:105-107)
+    bool panic;     // the reference would have panicked (poly.rs:84-86 or an index past the material list)
+};
+
+RTX_D V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+
+RTX_D const rtx_material* material_or_null(const DevScene& s, uint32_t id) {
+    return (id < s.n_materials) ? &s.mats[id] : nullptr;
+}
+
+// Poly::weighted_areas (poly.rs:78-89)
+RTX_D void weighted_areas(V3 p0, V3 p1, V3 p2, V3 point, float& a0, float& a1, float& a2, bool& panic) {
+    const float area = varea(p0, p1, p2);
+    a0 = varea(p0, p1, point) / area;
+    a1 = varea(p2, p0, point) / area;
+    a2 = varea(p1, p2, point) / area;
+    if (a0 > 1.0f || a1 > 1.0f || a2 > 1.0f) panic = true;
+}
+
+// Point, normal (and optionally colour) of a hit. `want_color` is false for
+// shadow-ray continuation, which only needs the normal and the material.
+RTX_D HitGeom hit_geometry(const DevScene& s, int prim_id, V3 o, V3 d, float t, bool want_color) {
+    HitGeom g;
+    g.panic = false;
+    g.p = o + vmult(d, t);
+    g.cd = col_new();
+    const uint32_t ref = s.prim_ref[prim_id];
+    const uint32_t idx = ref & 0x7fffffffu;
+    if (ref >> 31) {  // sphere
+        const float4 sp = s.sph[idx];
+        g.n = vnormalize(g.p - v3(sp.x, sp.y, sp.z));  // sphere.rs:109-113 (never flipped)
+        g.mat0 = s.sph_mat[idx];
+        if (want_color) {
+            const rtx_material* m = material_or_null(s, g.mat0);
+            if (m) g.cd = col_raw(m->diffuse); else g.panic = true;
+        }
+        return g;
+    }
+    const float* tp = s.tri_pos + (size_t)idx * 9;
+    const V3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+    const uint32_t flags = s.tri_flags[idx];
+    const uint32_t m0 = s.tri_mat[(size_t)idx * 3];
+    g.mat0 = m0;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    if (flags & (RTX_TRI_VERTEX_NORMAL | RTX_TRI_VERTEX_MATERIAL)) weighted_areas(p0, p1, p2, g.p, a0, a1, a2, g.panic);
+    V3 normal;
+    if (flags & RTX_TRI_VERTEX_NORMAL) {  // poly.rs:102-105
+        const float* tn = s.tri_nrm + (size_t)idx * 9;
+        normal = vmult(ld3(tn), a2) + vmult(ld3(tn + 3), a1) + vmult(ld3(tn + 6), a0);
+    } else {                              // poly.rs:96-100
+        normal = vcross(p1 - p0, p2 - p0);
+    }
+    normal = vnormalize(normal);          // poly.rs:185-196
+    if (vdot(normal, d) > 0.0f) normal = vinvert(normal);
+    g.n = normal;
+    if (want_color) {
+        if (flags & RTX_TRI_VERTEX_MATERIAL) {  // poly.rs:91-94
+            const rtx_material* ma = material_or_null(s, m0);
+            const rtx_material* mb = material_or_null(s, s.tri_mat[(size_t)idx * 3 + 1]);
+            const rtx_material* mc = material_or_null(s, s.tri_mat[(size_t)idx * 3 + 2]);
+            if (!ma || !mb || !mc) g.panic = true;
+            const Col da = ma ? col_raw(ma->diffuse) : col_new();
+            const Col db = mb ? col_raw(mb->diffuse) : col_new();
+            const Col dc = mc ? col_raw(mc->diffuse) : col_new();
+            g.cd = col_mult(da, a2) + col_mult(db, a1) + col_mult(dc, a0);
+        } else {                                // poly.rs:201
+            const rtx_material* m = material_or_null(s, m0);
+            if (m) g.cd = col_raw(m->diffuse); else g.panic = true;
+        }
+    }
+    return g;
+}
+
+// Intersection::reflective_ray (intersection.rs:42-48)
+RTX_D void reflective_ray(V3 dir, V3 point, V3 normal, V3& ro, V3& rd) {
+    const V3 d0 = vinvert(dir);
+    ro = point + vmult(normal, 0.0001f);
+    rd = vmult(normal, vdot(d0, normal) * 2.0f) - d0;
+}
+// Intersection::refractive_ray (intersection.rs:50-81); false = total internal reflection.
+RTX_D bool refractive_ray(V3 in_dir, V3 point, V3 normal, bool in_vacuum, V3& ro, V3& rd) {
+    const float n = in_vacuum ? 1.0f / 1.5f : 1.5f / 1.0f;
+    const float cos_in = vdot(normal, in_dir);
+    if (cos_in > 0.0f) normal = vinvert(normal);
+    const float c = vdot(in_dir, normal);
+    const float cos_phi_2 = 1.0f - n * n * (1.0f - c * c);
+    if (cos_phi_2 < 0.0f) return false;
+    const float cos_phi = sqrtf(cos_phi_2);
+    V3 term1 = in_dir - vmult(normal, c);
+    term1 = vmult(term1, n);
+    rd = term1 - vmult(normal, cos_phi);
+    ro = point - vmult(normal, 0.01f);
+    return true;
+}
+
+// Light::position / Light::get_dir for point and directional lights (scene/mod.rs:35-59).
+RTX_D V3 light_pos(const DevLight& l) {
+    return (l.type == RTX_LIGHT_POINT) ? v3(l.a[0], l.a[1], l.a[2]) : v3(0.0f, 0.0f, 0.0f);
+}
+RTX_D V3 light_dir(const DevLight& l, V3 point) {
+    if (l.type == RTX_LIGHT_DIRECTIONAL) return vinvert(v3(l.a[0], l.a[1], l.a[2]));
+    return vnormalize(v3(l.a[0], l.a[1], l.a[2]) - point);
+}
+// RayTracer::calculate_fattj (lib.rs:147-155)
+RTX_D float calculate_fattj(const DevLight& l, V3 point) {
+    if (l.type == RTX_LIGHT_DIRECTIONAL) return 1.0f;
+    const float dist = vdistance(point, light_pos(l));
+    return fminf(1.0f, 1.0f / (0.25f + 0.1f * dist + 0.01f * dist * dist));
+}
+// RayTracer::direct_lightning for one sample (lib.rs:171-199 with n == 1)
+RTX_D Col direct_lightning(const DevLight& l, V3 point, V3 normal, V3 ray_dir, Col cd, Col ks, float kt,
+                           float shininess, Col sj, float fattj) {
+    const float q = shininess * 128.0f;
+    const Col direct_light = col_mult(col_raw(l.color) * sj, fattj);
+    Col lightning = col_new();
+    const V3 dir = light_dir(l, point);
+    // diffuse_lightning (lib.rs:157-161)
+    const float a = 1.0f - kt;
+    const float b = fmaxf(0.0f, vdot(normal, dir));
+    const Col diffuse_light = col_mult(cd, a * b);
+    // specular_lightning (lib.rs:163-169)
+    const V3 v = vinvert(ray_dir);
+    float t = vdot(normal, dir);
+    V3 rj = vmult(vmult(normal, t), 2.0f);
+    rj = rj - dir;
+    t = fmaxf(vdot(rj, v), 0.0f);
+    const Col specular_light = col_mult(ks, powf(t, q));
+    Col sample = direct_light * (diffuse_light + specular_light);
+    sample = col_init(sample.r / 1.0f, sample.g / 1.0f, sample.b / 1.0f);
+    lightning = lightning + sample;
+    return lightning;
+}

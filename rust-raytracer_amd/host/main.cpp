@@ -1,0 +1,66 @@
+// rstracer -- command line front end with the reference's flags (src/main.rs:40-79):
+//   -h  -b  -s SIZE  -a SAMPLES  -d DEPTH  -i SCENE  -o OUT
+// Defaults as in main.rs:63-67: size 100, samples 10, depth 10, scene test01,
+// output img.bmp. Unparsable numbers fall back to the default (main.rs:20-25).
+// `-b` is accepted for compatibility: the GPU path always uses its own BVH.
+// Additions: -W/-H for non-square frames, -g DEVICE.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "rstracer.hpp"
+
+static long get_opt(const char* s, long dflt) {
+    if (!s) return dflt;
+    char* end = nullptr;
+    long v = std::strtol(s, &end, 10);
+    return (end == s || *end != 0 || v < 0) ? dflt : v;
+}
+
+int main(int argc, char** argv) {
+    const char *s = nullptr, *a = nullptr, *d = nullptr, *i = nullptr, *o = nullptr, *W = nullptr, *H = nullptr, *g = nullptr;
+    for (int k = 1; k < argc; ++k) {
+        const std::string f = argv[k];
+        auto val = [&](const char** dst) {
+            if (k + 1 >= argc) { std::fprintf(stderr, "Argument to option '%s' missing.\n", f.c_str()); std::exit(101); }
+            *dst = argv[++k];
+        };
+        if (f == "-h" || f == "--help") {
+            std::printf("Usage: %s [options]\n\nOptions:\n"
+                        "    -h --help           Print this help menu\n"
+                        "    -b --bvh            Optimize scene intersection with BVH-tree\n"
+                        "    -s --size -s 500    The width and height of the image to be generated\n"
+                        "    -a --arealight-samples -a 1000\n                        The number of times to sample the area lights\n"
+                        "    -d --depth -d 10    The depth of the recursion in the main loop\n"
+                        "    -i --scene -i test01\n                        The name of a scene located in the ./scenes directory\n"
+                        "    -o --out -o image.bmp\n                        The name of the image to be generated\n", argv[0]);
+            return 0;
+        } else if (f == "-b" || f == "--bvh") {
+        } else if (f == "-s" || f == "--size") val(&s);
+        else if (f == "-a" || f == "--arealight-samples") val(&a);
+        else if (f == "-d" || f == "--depth") val(&d);
+        else if (f == "-i" || f == "--scene") val(&i);
+        else if (f == "-o" || f == "--out") val(&o);
+        else if (f == "-W") val(&W);
+        else if (f == "-H") val(&H);
+        else if (f == "-g") val(&g);
+        else { std::fprintf(stderr, "Unrecognized option: '%s'.\n", f.c_str()); return 101; }
+    }
+    const long size = get_opt(s, 100);
+    const long width = get_opt(W, size), height = get_opt(H, size);
+    const long samples = get_opt(a, 10), depth = get_opt(d, 10);
+    const std::string scene_path = std::string("scenes/") + (i ? i : "test01") + ".ascii";   // main.rs:34-37
+    const std::string out = std::string(o ? o : "img") + ".bmp";                             // main.rs:67
+    try {
+        rstracer::SceneParser parser(scene_path);
+        rstracer::Scene scene = parser.parse_scene();
+        rstracer::RayTracer tracer = rstracer::RayTracer::init((uint32_t)width, (uint32_t)height, (size_t)depth, (size_t)samples);
+        tracer.set_scene(std::make_unique<rstracer::GpuScene>(scene, (int)get_opt(g, 0)));
+        tracer.trace_rays().save(out);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "thread 'main' panicked at '%s'\n", e.what());   // the reference aborts with a panic message
+        return 101;
+    }
+    return 0;
+}
