@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the frame hot path on N MI355X GPUs of one node.
+
+Workload (BASELINE.json configs[2], the largest single-GPU configuration): synthetic
+1 002 528-triangle tessellated height field + 4 point lights at 1920x1080, depth 10
+(the reference's default; the scene has no reflective or refractive material, so one
+level of rays is traced: primary + 4 shadow rays per hit). One step = one frame, scene
+and BVH resident in HBM. N > 1: the frame is sharded by interleaved 8x8 tiles, the
+scene is broadcast once from rank 0 over RCCL and every step ends with an all-gather of
+the tile slabs (strong scaling: the frame is fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (spec)
+
+
+def cpu_baseline(flat, width, height, depth, samples, stride):
+    """Times the CPU oracle (a single-threaded C++ restatement of the reference renderer,
+    which is itself single-threaded) on a stratified pixel subset of the same frame."""
+    from oracle import oracle_ffi
+    oracle_ffi.build()
+    scene = oracle_ffi.OracleScene.from_flat(flat)
+    out = scene.render(width, height, depth, samples, stride=(stride, stride), threads=1)
+    st = out["stats"]
+    rays = st["primary_rays"] + st["shadow_rays"] + st["reflect_rays"] + st["refract_rays"]
+    npix = len(range(0, width, stride)) * len(range(0, height, stride))
+    return {"value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": "%d pixels (every %dth in x and y) of the %dx%d frame, %d rays, %.1f s; exhaustive loop over all primitives"
+                      % (npix, stride, width, height, rays, st["seconds"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=708, help="height-field cells per side (708 -> 1 002 528 triangles)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--spec", type=float, default=0.0)
+    ap.add_argument("--glass", type=int, default=0)
+    ap.add_argument("--cpu-stride", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rtx = importlib.import_module("rust-raytracer_amd")
+    synth = importlib.import_module("rust-raytracer_amd.synth")
+    rdist = importlib.import_module("rust-raytracer_amd.dist")
+
+    flat = synth.heightfield_scene(args.grid, spec=args.spec, glass_lattice=args.glass) if rank == 0 else None
+    t_b0 = time.time()
+    if world > 1:
+        flat = rdist.broadcast_scene(flat, 0, dev)
+    bcast_ms = (time.time() - t_b0) * 1e3
+
+    ctx = rtx.Context(local_rank)
+    ctx.set_scene(flat)
+    build = ctx.build()
+    w, h = args.width, args.height
+    tpr = rtx.tiles_per_rank(w, h, world)
+    slab = torch.zeros(tpr * 192, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) if world > 1 else slab
+    image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+
+    def step():
+        st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slab.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, slab)
+            torch.cuda.current_stream().synchronize()
+        ctx.assemble_tiles(w, h, world, gathered.data_ptr(), image.data_ptr())
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    acc = {"closest_ms": 0.0, "shadow_ms": 0.0, "closest_launches": 0, "shadow_launches": 0, "render_ms": 0.0,
+           "closest_rays": 0, "shadow_rays": 0, "traced": 0, "reference": 0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+        acc["closest_ms"] += st.closest_ms
+        acc["shadow_ms"] += st.shadow_ms
+        acc["closest_launches"] += st.closest_launches
+        acc["shadow_launches"] += st.shadow_launches
+        acc["render_ms"] += st.render_ms
+        acc["closest_rays"] += st.primary_rays + st.reflect_rays + st.refract_rays - st.skipped_rays
+        acc["shadow_rays"] += st.shadow_rays
+        acc["traced"] += st.traced_rays
+        acc["reference"] += st.reference_rays
+    sync()
+    elapsed = time.perf_counter() - t0
+    total_traced = acc["traced"]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tr = torch.tensor([acc["traced"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        total_traced = float(tr.item())
+
+    if rank == 0:
+        n_prims = flat.n_prims
+        b_ray = synth.bytes_per_ray(n_prims)
+        # dominant kernel = the traversal kernel with the larger share of device time on this rank
+        if acc["shadow_ms"] >= acc["closest_ms"] and acc["shadow_launches"]:
+            kname, kms, kl, krays = "k_shadow (any-hit traversal)", acc["shadow_ms"], acc["shadow_launches"], acc["shadow_rays"]
+        else:
+            kname, kms, kl, krays = "k_trace_queue (closest-hit traversal)", acc["closest_ms"], acc["closest_launches"], acc["closest_rays"]
+        avg_ms = kms / max(kl, 1)
+        rays_per_launch = krays / max(kl, 1)
+        achieved = rays_per_launch * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/sec (primary+shadow+secondary) per GPU and per node; frame time",
+            "value": total_traced / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %d-triangle tessellated height field + 4 point lights at %dx%d, depth %d, "
+                                   "LBVH traversal, scene and BVH resident in HBM" % (flat.n_tris, w, h, args.depth),
+                       "n_prims": n_prims, "width": w, "height": h, "depth": args.depth,
+                       "parallelism": "tile-sharded x%d" % world if world > 1 else "single GPU"},
+            "rays_per_frame": total_traced / args.steps,
+            "device_frame_ms_rank0": acc["render_ms"] / args.steps,
+            "build_ms": build["build_ms"], "upload_ms": build["upload_ms"], "scene_broadcast_ms": bcast_ms,
+            "bvh": {k: build[k] for k in ("n_nodes", "n_leaves", "max_depth", "key_bits", "uses_bvh")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                         "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat, w, h, args.depth, 10, args.cpu_stride)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,9 +125,12 @@ typedef struct rtx_render_stats {
     uint64_t shaded_nodes;
     uint64_t panic_pixels;      /* shaded nodes where the reference would have panicked (poly.rs:84-86,93) */
     float    render_ms;         /* device time of the frame, scene resident, excludes the copy of the image to the host */
-    float    trace_ms;          /* device time inside the traversal kernels (closest-hit + shadow) */
-    uint32_t trace_launches;    /* number of traversal-kernel launches behind trace_ms */
+    float    closest_ms;        /* device time inside the closest-hit traversal kernel (primary + secondary rays) */
+    float    shadow_ms;         /* device time inside the shadow-ray traversal kernel */
+    uint32_t closest_launches;  /* launches behind closest_ms */
+    uint32_t shadow_launches;   /* launches behind shadow_ms */
     uint32_t batches;           /* pixel batches the frame was split into */
+    uint32_t reserved;
 } rtx_render_stats;
 
 typedef struct rtx_context rtx_context;

@@ -76,7 +76,7 @@ def lib():
         L.orc_scene_parse.restype = C.c_void_p
         L.orc_scene_parse.argtypes = [C.c_char_p]
         L.orc_scene_from_desc.restype = C.c_void_p
-        L.orc_scene_from_desc.argtypes = [C.POINTER(RtxSceneDesc)]
+        L.orc_scene_from_desc.argtypes = [C.c_void_p]
         L.orc_scene_free.argtypes = [C.c_void_p]
         L.orc_scene_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 5
         L.orc_scene_flatten.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.POINTER(RtxCamera)]
@@ -166,7 +166,8 @@ class OracleScene:
     @classmethod
     def from_flat(cls, flat):
         d, keep = flat.desc()
-        return cls(lib().orc_scene_from_desc(C.byref(d)))
+        h = lib().orc_scene_from_desc(C.cast(C.byref(d), C.c_void_p))
+        return cls(h)
 
     def close(self):
         if self._h:

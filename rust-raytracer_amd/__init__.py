@@ -76,8 +76,9 @@ class BuildStats(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("reflect_rays", C.c_uint64),
                 ("refract_rays", C.c_uint64), ("skipped_rays", C.c_uint64), ("shaded_nodes", C.c_uint64),
-                ("panic_pixels", C.c_uint64), ("render_ms", C.c_float), ("trace_ms", C.c_float),
-                ("trace_launches", C.c_uint32), ("batches", C.c_uint32)]
+                ("panic_pixels", C.c_uint64), ("render_ms", C.c_float), ("closest_ms", C.c_float),
+                ("shadow_ms", C.c_float), ("closest_launches", C.c_uint32), ("shadow_launches", C.c_uint32),
+                ("batches", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

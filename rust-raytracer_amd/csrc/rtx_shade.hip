@@ -541,7 +541,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     EventPool ev{ctx};
     hipEvent_t f0 = ev.next(), f1 = ev.next();
     if (!f0 || !f1) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> closest_events, shadow_events;
     RTX_HIP(ctx, hipEventRecord(f0, st));
     uint32_t n_batches = 0;
     uint64_t cur_batch = batch;
@@ -563,7 +563,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             RTX_HIP(ctx, hipEventRecord(a, st));
             dispatch_trace(stack_trace, s, wk.q[qi], &wk.ctl->n_rays[qi], &wk.ctl->overflow, n_rays, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
-            trace_events.emplace_back(a, b);
+            closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
@@ -574,7 +574,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 else if (stack_shadow == 64) launch_shadow<64>(s, wk, depth - level, tasks, any_shadow, st);
                 else launch_shadow<128>(s, wk, depth - level, tasks, any_shadow, st);
                 RTX_HIP(ctx, hipEventRecord(d, st));
-                trace_events.emplace_back(c, d);
+                shadow_events.emplace_back(c, d);
             }
             hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level);
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
@@ -623,14 +623,19 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, f0, f1);
         rs.render_ms = ms;
-        float tsum = 0.0f;
-        for (auto& p : trace_events) {
-            float e = 0.0f;
-            (void)hipEventElapsedTime(&e, p.first, p.second);
-            tsum += e;
-        }
-        rs.trace_ms = tsum;
-        rs.trace_launches = (uint32_t)trace_events.size();
+        auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs) {
+            float total = 0.0f;
+            for (auto& p : evs) {
+                float e = 0.0f;
+                (void)hipEventElapsedTime(&e, p.first, p.second);
+                total += e;
+            }
+            return total;
+        };
+        rs.closest_ms = sum_ms(closest_events);
+        rs.shadow_ms = sum_ms(shadow_events);
+        rs.closest_launches = (uint32_t)closest_events.size();
+        rs.shadow_launches = (uint32_t)shadow_events.size();
         rs.batches = n_batches;
         *stats = rs;
     }
