@@ -82,13 +82,28 @@ __global__ __launch_bounds__(kThreads) void k_bounds(DevScene s, float4* __restr
         lo[k] = wave_min(lo[k]);
         hi[k] = wave_max(hi[k]);
     }
+    __shared__ float slo[kThreads / 64][6], shi[kThreads / 64][6];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&sb->cmin[k], enc_f32(lo[k]));
-            atomicMax(&sb->cmax[k], enc_f32(hi[k]));
-            atomicMin(&sb->bmin[k], enc_f32(lo[3 + k]));
-            atomicMax(&sb->bmax[k], enc_f32(hi[3 + k]));
+        for (int k = 0; k < 6; ++k) {
+            slo[threadIdx.x >> 6][k] = lo[k];
+            shi[threadIdx.x >> 6][k] = hi[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {   // one atomic per workgroup and value
+        const int k = threadIdx.x;
+        float a = slo[0][k], b = shi[0][k];
+        for (int j = 1; j < kThreads / 64; ++j) {
+            a = fminf(a, slo[j][k]);
+            b = fmaxf(b, shi[j][k]);
+        }
+        if (k < 3) {
+            atomicMin(&sb->cmin[k], enc_f32(a));
+            atomicMax(&sb->cmax[k], enc_f32(b));
+        } else {
+            atomicMin(&sb->bmin[k - 3], enc_f32(a));
+            atomicMax(&sb->bmax[k - 3], enc_f32(b));
         }
     }
 }
@@ -379,12 +394,12 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
 __device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
                                          uint32_t* leaf_count) {
     if (c >= n - 1) {
-        atomicAdd(leaf_count, 1u);
+        ++*leaf_count;
         return (int)~(((uint32_t)(c - (n - 1)) << 3) | 0u);
     }
     const int size = rng_last[c] - rng_first[c] + 1;
     if (size <= RTX_LEAF_MAX) {
-        atomicAdd(leaf_count, 1u);
+        ++*leaf_count;
         return (int)~(((uint32_t)rng_first[c] << 3) | (uint32_t)(size - 1));
     }
     return c;
@@ -393,21 +408,31 @@ __global__ __launch_bounds__(kThreads) void k_emit(int n, const int* __restrict_
                                                     const int* __restrict__ rng_first, const int* __restrict__ rng_last,
                                                     const float4* __restrict__ nmin, const float4* __restrict__ nmax,
                                                     BvhNode* __restrict__ nodes, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_nodes, s_leaves;
+    if (threadIdx.x == 0) s_nodes = s_leaves = 0;
+    __syncthreads();
     const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n - 1) return;
-    const int size = rng_last[i] - rng_first[i] + 1;
-    if (size <= RTX_LEAF_MAX) return;   // absorbed into a leaf of an ancestor
-    const int l = child_l[i], r = child_r[i];
-    const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
-    BvhNode nd;
-    nd.q0 = make_float4(la.x, la.y, la.z, lb.x);
-    nd.q1 = make_float4(lb.y, lb.z, ra.x, ra.y);
-    nd.q2 = make_float4(ra.z, rb.x, rb.y, rb.z);
-    const int lr = child_ref(l, n, rng_first, rng_last, &counts[1]);
-    const int rr = child_ref(r, n, rng_first, rng_last, &counts[1]);
-    nd.q3 = make_float4(__int_as_float(lr), __int_as_float(rr), 0.0f, 0.0f);
-    nodes[i] = nd;
-    atomicAdd(&counts[0], 1u);
+    uint32_t my_nodes = 0, my_leaves = 0;
+    if (i < n - 1 && rng_last[i] - rng_first[i] + 1 > RTX_LEAF_MAX) {   // smaller subtrees are absorbed into a leaf of an ancestor
+        const int l = child_l[i], r = child_r[i];
+        const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
+        BvhNode nd;
+        nd.q0 = make_float4(la.x, la.y, la.z, lb.x);
+        nd.q1 = make_float4(lb.y, lb.z, ra.x, ra.y);
+        nd.q2 = make_float4(ra.z, rb.x, rb.y, rb.z);
+        const int lr = child_ref(l, n, rng_first, rng_last, &my_leaves);
+        const int rr = child_ref(r, n, rng_first, rng_last, &my_leaves);
+        nd.q3 = make_float4(__int_as_float(lr), __int_as_float(rr), 0.0f, 0.0f);
+        nodes[i] = nd;
+        my_nodes = 1;
+    }
+    if (my_nodes) atomicAdd(&s_nodes, my_nodes);     // LDS atomics
+    if (my_leaves) atomicAdd(&s_leaves, my_leaves);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_nodes) atomicAdd(&counts[0], s_nodes);
+        if (s_leaves) atomicAdd(&counts[1], s_leaves);
+    }
 }
 
 // Traversal records, in `order` (sorted ids) or in id order when order == nullptr.

@@ -123,20 +123,18 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
 __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(CamSetup cam, Work wk, uint64_t first, uint32_t n, uint32_t rank,
                                                       uint32_t world, uint32_t tiles_x, uint32_t n_tiles) {
     const uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x;
-    bool valid = false;
     if (i < n) {
         const uint64_t g = first + i;
         const uint64_t tile = (g >> 6) * world + rank;
         const uint32_t lane = (uint32_t)(g & 63);
         const uint32_t x = (uint32_t)(tile % tiles_x) * RTX_TILE + (lane & 7u);
         const uint32_t y = (uint32_t)(tile / tiles_x) * RTX_TILE + (lane >> 3);
-        valid = tile < n_tiles && x < cam.w && y < cam.h;
+        const bool valid = tile < n_tiles && x < cam.w && y < cam.h;
         V3 d = v3(0.0f, 0.0f, 0.0f);
         if (valid) d = compute_ray_dir(cam, (float)x, (float)(cam.h - y - 1));   // lib.rs:263
         wk.q[0].o[i] = make_float4(cam.cam_pos.x, cam.cam_pos.y, cam.cam_pos.z, u2f((uint32_t)g));
         wk.q[0].d[i] = make_float4(d.x, d.y, d.z, u2f(valid ? (RTX_RAY_VALID | RTX_RAY_VACUUM) : 0u));
     }
-    wave_count(&wk.ctl->stat[ST_PRIMARY], valid);
 }
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201).
@@ -158,43 +156,74 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue 
 }
 
 // Forward step 1: every hit becomes a shading node (shade_intersection is only
-// entered for hits: lib.rs:264-271, 232-236, 243-247).
+// entered for hits: lib.rs:264-271, 232-236, 243-247). A workgroup takes a chunk of
+// 256 * kShadeItems consecutive rays, counts its hits first and reserves their node
+// slots with ONE atomic, so the node order follows the ray order inside a chunk and
+// the global counter sees ~n/2048 atomics instead of one per wavefront.
+constexpr int kShadeItems = 8;
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi) {
+    __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
+    __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     const uint32_t n = ctl->n_rays[qi];
     const uint32_t pool_base = ctl->pool_base;
     const RayQueue q = wk.q[qi];
-    const uint32_t stride = gridDim.x * RTX_BLOCK;
-    for (uint32_t base = blockIdx.x * RTX_BLOCK; base < n; base += stride) {   // wave-uniform trip count
-        const uint32_t i = base + threadIdx.x;
-        bool want = false;
-        uint2 hit = make_uint2(0xffffffffu, 0u);
-        if (i < n) {
-            hit = q.hit[i];
-            want = (int)hit.x >= 0;
+    const uint32_t chunk = RTX_BLOCK * kShadeItems;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk) {   // block-uniform trip count
+        uint2 hit[kShadeItems];
+        uint32_t pre[kShadeItems];
+#pragma unroll
+        for (int k = 0; k < kShadeItems; ++k) {
+            const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
+            hit[k] = (i < n) ? q.hit[i] : make_uint2(0xffffffffu, 0u);
+            const uint64_t m = __ballot((int)hit[k].x >= 0);
+            pre[k] = (uint32_t)__popcll(m & lt);
+            if (lane == 0) cnt[k][w] = (uint32_t)__popcll(m);
         }
-        uint32_t node = wave_alloc(&ctl->n_nodes, want);
-        if (want && (node >= wk.cap_rays || pool_base + node >= wk.cap_pool)) {
-            ctl->overflow = 1;
-            want = false;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int k = 0; k < kShadeItems; ++k)
+                for (int j = 0; j < RTX_BLOCK / 64; ++j) total += cnt[k][j];
+            s_base = total ? atomicAdd(&ctl->n_nodes, total) : 0u;
         }
+        __syncthreads();
+        uint32_t run = s_base;
         bool panic = false;
-        if (want) {
+#pragma unroll
+        for (int k = 0; k < kShadeItems; ++k) {
+            uint32_t before = 0, row = 0;
+#pragma unroll
+            for (int j = 0; j < RTX_BLOCK / 64; ++j) {
+                const uint32_t c = cnt[k][j];
+                if (j < w) before += c;
+                row += c;
+            }
+            const uint32_t node = run + before + pre[k];
+            run += row;
+            if ((int)hit[k].x < 0) continue;
+            if (node >= wk.cap_rays || pool_base + node >= wk.cap_pool) {
+                ctl->overflow = 1;
+                continue;
+            }
+            const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
             const float4 o4 = q.o[i], d4 = q.d[i];
             const V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
-            const HitGeom g = hit_geometry(s, (int)hit.x, o, d, u2f(hit.y), true);
-            panic = g.panic;
+            const HitGeom g = hit_geometry(s, (int)hit[k].x, o, d, u2f(hit[k].y), true);
+            panic |= g.panic;
             const uint32_t slot = pool_base + node;
-            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (panic ? 4u : 0u);
+            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u);
             wk.nP[node] = make_float4(g.p.x, g.p.y, g.p.z, u2f(g.mat0));
             wk.nN[node] = make_float4(g.n.x, g.n.y, g.n.z, u2f(nflags));
             wk.nV[node] = make_float4(d.x, d.y, d.z, u2f(slot));
             wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);
             wk.pLink[slot] = f2u(o4.w);
         }
-        wave_count(&ctl->stat[ST_NODES], want);
-        wave_count(&ctl->stat[ST_PANIC], panic);
+        if (panic) atomicAdd(&ctl->stat[ST_PANIC], 1ull);   // rare
+        __syncthreads();
     }
 }
 
@@ -350,6 +379,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
 }
 
 __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t cap_rays) {
+    ctl->stat[ST_NODES] += min(ctl->n_nodes, cap_rays);
     ctl->pool_base += min(ctl->n_nodes, cap_rays);
     ctl->level_start[level + 1] = ctl->pool_base;
     ctl->n_nodes = 0;
@@ -522,6 +552,15 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const uint64_t tiles_per_rank = rtx_tiles_per_rank(w, h, world);
     const uint64_t tiles_local = (rank < n_tiles) ? (n_tiles - rank + world - 1) / world : 0;
     const uint64_t rays_local = tiles_local * 64;
+    uint64_t primary = 0;   // pixels of this rank's tiles that lie inside the image
+    {
+        const uint32_t edge_w = w - (tiles_x - 1) * RTX_TILE, edge_h = h - (tiles_y - 1) * RTX_TILE;
+        for (uint64_t tile = rank; tile < n_tiles; tile += world) {
+            const uint32_t tw = (tile % tiles_x == tiles_x - 1) ? edge_w : RTX_TILE;
+            const uint32_t th = (tile / tiles_x == tiles_y - 1) ? edge_h : RTX_TILE;
+            primary += (uint64_t)tw * th;
+        }
+    }
     RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, tiles_per_rank * 64 * 3, st));
 
     uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays_local, 64));
@@ -564,7 +603,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             dispatch_trace(stack_trace, s, wk.q[qi], &wk.ctl->n_rays[qi], &wk.ctl->overflow, n_rays, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -613,7 +652,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         Ctl hc;
         RTX_HIP(ctx, hipMemcpy(&hc, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
         rtx_render_stats rs{};
-        rs.primary_rays = hc.stat[ST_PRIMARY];
+        rs.primary_rays = primary;
         rs.shadow_rays = hc.stat[ST_SHADOW];
         rs.reflect_rays = hc.stat[ST_REFLECT];
         rs.refract_rays = hc.stat[ST_REFRACT];

@@ -1,0 +1,44 @@
+"""GPU frames against the committed golden fixtures (tests/golden/frames_100x100.npz)."""
+import numpy as np
+import pytest
+
+from conftest import BUNDLED, GOLDEN_DIR, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN_DIR + "/frames_100x100.npz")
+
+
+@pytest.mark.parametrize("name", BUNDLED)
+def test_gpu_frame_matches_golden(name, rtx, gpu_ctx_factory, golden):
+    ctx = gpu_ctx_factory(rtx.parse_scene(scene_path(name)))
+    prim, t, _ = ctx.primary_hits(100, 100)
+    rgb, st = ctx.render(100, 100, 10, 10)
+    assert np.array_equal(prim, golden[name + "_prim"])
+    hit = prim >= 0
+    assert np.array_equal(t.view(np.uint32)[hit], golden[name + "_t"].view(np.uint32)[hit])
+    diff = np.abs(rgb.astype(int) - golden[name + "_rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
+    counts = golden[name + "_counts"]
+    assert [st.primary_rays, st.shadow_rays, st.reflect_rays, st.refract_rays, st.shaded_nodes, st.skipped_rays] == \
+        [int(counts[i]) for i in (0, 1, 2, 3, 4, 5)]
+
+
+def test_cli_writes_the_same_bmp(rtx, golden, tmp_path):
+    """The command line tool with the reference's flags (src/main.rs:45-51) end to end."""
+    import subprocess
+    from conftest import ROOT
+    out = tmp_path / "img"
+    subprocess.check_call([rtx.CLI_PATH, "-i", "test04", "-s", "100", "-d", "10", "-o", str(out)], cwd=ROOT)
+    data = open(str(out) + ".bmp", "rb").read()
+    assert data[:2] == b"BM"
+    w, h = int.from_bytes(data[18:22], "little"), int.from_bytes(data[22:26], "little")
+    off = int.from_bytes(data[10:14], "little")
+    assert (w, h) == (100, 100)
+    row = (w * 3 + 3) & ~3
+    img = np.frombuffer(data[off:off + row * h], np.uint8).reshape(h, row)[:, :w * 3].reshape(h, w, 3)[::-1, :, ::-1]
+    diff = np.abs(img.astype(int) - golden["test04_rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
