@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--glass", type=int, default=0)
     ap.add_argument("--cpu-stride", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="traversal kernel variant (rtx_set_option trace_variant)")
+    ap.add_argument("--tune", type=str, default="", help="comma-separated tune0..3 overrides (experiments)")
     args = ap.parse_args()
 
     import torch
@@ -82,6 +84,10 @@ def main():
     bcast_ms = (time.time() - t_b0) * 1e3
 
     ctx = rtx.Context(local_rank)
+    if args.variant:
+        ctx.set_option("trace_variant", args.variant)
+    for i, v in enumerate([x for x in args.tune.split(",") if x]):
+        ctx.set_option("tune%d" % i, int(v))
     ctx.set_scene(flat)
     build = ctx.build()
     w, h = args.width, args.height

@@ -147,7 +147,9 @@ const char* rtx_last_error(const rtx_context* ctx);
 /* Tuning knobs (no counterpart in the reference):
  *   "force_mode"   0 = automatic, 1 = exhaustive kernel, 2 = BVH (takes effect at the next rtx_build)
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^22)
- *   "pool_factor"  retained shading nodes per batch pixel (default 4) */
+ *   "pool_factor"  retained shading nodes per batch pixel (default 4)
+ *   "trace_variant" 0 = one ray per lane, grid-stride (default), 1 = persistent wavefronts with lane refill
+ *   "tune0".."tune3" traversal tuning: refill threshold, phase-vote weight (variant 1), workgroups per CU (1..8) */
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
 
 /* ---- scene ---------------------------------------------------------------

@@ -74,6 +74,8 @@ int rtx_create(int device, rtx_context** out_ctx) {
     rtx_context* ctx = new (std::nothrow) rtx_context();
     if (!ctx) return rtx_fail(nullptr, RTX_ERR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -104,6 +106,12 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "force_mode must be 0, 1 or 2");
         ctx->opt_force_mode = value;
         ctx->built = false;   // takes effect at the next rtx_build
+    } else if (k == "trace_variant") {
+        if (value < 0 || value > 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "trace_variant must be 0 or 1");
+        ctx->opt_trace_variant = value;
+    } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
+        ctx->opt_tune[k[4] - '0'] = (int32_t)value;
+        for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
     } else if (k == "batch_pixels") {
         if (value < 64) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "batch_pixels must be at least 64");
         ctx->opt_batch_pixels = value;
@@ -213,6 +221,7 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
     s.sph_mat = d_smat;
     s.mats = d_mats;
     s.lights = d_lights;
+    for (int i = 0; i < 4; ++i) s.tune[i] = ctx->opt_tune[i];
     ctx->ds = s;
     ctx->camera = d->camera;
     ctx->build_stats = rtx_build_stats{};

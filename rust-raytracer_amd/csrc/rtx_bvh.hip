@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "rtx_internal.h"
+#include "rtx_traverse.h"
 
 namespace {
 
@@ -391,6 +392,11 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
     }
 }
 
+// Reference to binary node c as a child of a traversal node: a leaf (single primitive
+// or a collapsed subtree of at most RTX_LEAF_MAX primitives) or an inner node.
+__device__ __forceinline__ bool is_expandable(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last) {
+    return c < n - 1 && (rng_last[c] - rng_first[c] + 1) > RTX_LEAF_MAX;
+}
 __device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
                                          uint32_t* leaf_count) {
     if (c >= n - 1) {
@@ -404,25 +410,95 @@ __device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ r
     }
     return c;
 }
-__global__ __launch_bounds__(kThreads) void k_emit(int n, const int* __restrict__ child_l, const int* __restrict__ child_r,
-                                                    const int* __restrict__ rng_first, const int* __restrict__ rng_last,
-                                                    const float4* __restrict__ nmin, const float4* __restrict__ nmax,
-                                                    BvhNode* __restrict__ nodes, uint32_t* __restrict__ counts) {
+
+// Power-of-two grid step (as a biased f32 exponent) such that extent / step <= 254.
+__device__ __forceinline__ uint32_t step_exponent(float extent) {
+    if (!(extent > 0.0f)) return 1u;
+    int ex;
+    (void)frexpf(extent / 254.0f, &ex);    // extent/254 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= extent/254
+    return (uint32_t)min(max(ex + 127, 1), 254);
+}
+
+// Emits the 4-wide traversal nodes: every inner node of the binary tree at EVEN depth
+// absorbs its two children (where they are inner nodes themselves) and so gets 2-4
+// children; odd-depth inner nodes disappear. Child boxes are quantised to 8 bits per
+// plane relative to the node's own box, rounded outward and verified with the same
+// fma the traversal uses, so a quantised box always contains the padded box.
+__global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict__ child_l, const int* __restrict__ child_r,
+                                                     const int* __restrict__ parent, const int* __restrict__ rng_first,
+                                                     const int* __restrict__ rng_last, const float4* __restrict__ nmin,
+                                                     const float4* __restrict__ nmax, BvhNode* __restrict__ nodes,
+                                                     uint32_t* __restrict__ counts) {
     __shared__ uint32_t s_nodes, s_leaves;
     if (threadIdx.x == 0) s_nodes = s_leaves = 0;
     __syncthreads();
     const int i = blockIdx.x * kThreads + threadIdx.x;
     uint32_t my_nodes = 0, my_leaves = 0;
-    if (i < n - 1 && rng_last[i] - rng_first[i] + 1 > RTX_LEAF_MAX) {   // smaller subtrees are absorbed into a leaf of an ancestor
-        const int l = child_l[i], r = child_r[i];
-        const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
+    bool emit = i < n - 1 && (rng_last[i] - rng_first[i] + 1) > RTX_LEAF_MAX;
+    if (emit) {
+        int depth = 0;
+        for (int p = parent[i]; p >= 0; p = parent[p]) ++depth;
+        emit = (depth & 1) == 0;
+    }
+    if (emit) {
+        int ch[4];
+        int nc = 0;
+        const int lr[2] = {child_l[i], child_r[i]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = lr[k];
+            if (is_expandable(c, n, rng_first, rng_last)) {
+                ch[nc++] = child_l[c];
+                ch[nc++] = child_r[c];
+            } else {
+                ch[nc++] = c;
+            }
+        }
+        const float4 bmn = nmin[i], bmx = nmax[i];
+        const float org[3] = {bmn.x, bmn.y, bmn.z};
+        const float ext[3] = {bmx.x - bmn.x, bmx.y - bmn.y, bmx.z - bmn.z};
+        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, eb[3];
+        float cmn[4][3], cmx[4][3];
+        for (int k = 0; k < nc; ++k) {
+            const float4 a = nmin[ch[k]], b = nmax[ch[k]];
+            cmn[k][0] = a.x; cmn[k][1] = a.y; cmn[k][2] = a.z;
+            cmx[k][0] = b.x; cmx[k][1] = b.y; cmx[k][2] = b.z;
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            uint32_t e = step_exponent(ext[ax]);
+            for (;;) {   // raise the step until every child plane is representable (at most a few rounds)
+                const float step = __uint_as_float(e << 23);
+                bool ok = true;
+                uint32_t lo_pack = 0, hi_pack = 0;
+                for (int k = 0; k < nc; ++k) {
+                    float lo = floorf((cmn[k][ax] - org[ax]) / step);
+                    lo = fminf(fmaxf(lo, 0.0f), 255.0f);
+                    while (lo > 0.0f && __builtin_fmaf(lo, step, org[ax]) > cmn[k][ax]) lo -= 1.0f;
+                    float hi = ceilf((cmx[k][ax] - org[ax]) / step);
+                    hi = fminf(fmaxf(hi, 0.0f), 255.0f);
+                    while (hi < 255.0f && __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) hi += 1.0f;
+                    if (__builtin_fmaf(lo, step, org[ax]) > cmn[k][ax] || __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) ok = false;
+                    lo_pack |= (uint32_t)lo << (8 * k);
+                    hi_pack |= (uint32_t)hi << (8 * k);
+                }
+                if (ok || e >= 254u) {
+                    qlo[ax] = lo_pack;
+                    qhi[ax] = hi_pack;
+                    eb[ax] = e;
+                    break;
+                }
+                ++e;
+            }
+        }
+        int ref[4] = {0, 0, 0, 0};
+        for (int k = 0; k < nc; ++k) ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves);
         BvhNode nd;
-        nd.q0 = make_float4(la.x, la.y, la.z, lb.x);
-        nd.q1 = make_float4(lb.y, lb.z, ra.x, ra.y);
-        nd.q2 = make_float4(ra.z, rb.x, rb.y, rb.z);
-        const int lr = child_ref(l, n, rng_first, rng_last, &my_leaves);
-        const int rr = child_ref(r, n, rng_first, rng_last, &my_leaves);
-        nd.q3 = make_float4(__int_as_float(lr), __int_as_float(rr), 0.0f, 0.0f);
+        nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
+                          eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24));
+        nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+        nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
+        nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], 0u, 0u);
         nodes[i] = nd;
         my_nodes = 1;
     }
@@ -623,8 +699,8 @@ int rtx_bvh_build(rtx_context* ctx) {
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
         TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
-        hipLaunchKernelGGL(k_emit, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, child_l, child_r,
-                           rng_first, rng_last, nmin, nmax, nodes, counts);
+        hipLaunchKernelGGL(k_emit4, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, child_l, child_r,
+                           parent, rng_first, rng_last, nmin, nmax, nodes, counts);
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
         uint32_t hcounts[2] = {0, 0};
         uint8_t root_h = 0;
@@ -633,10 +709,23 @@ int rtx_bvh_build(rtx_context* ctx) {
         TRY_HIP(hipStreamSynchronize(st));
         bs.n_nodes = hcounts[0];
         bs.n_leaves = hcounts[1];
-        bs.max_depth = root_h;
+        (void)root_h;
+        bs.max_depth = levels;   // height of the binary tree; the 4-wide tree has about half of it
         s.recs = recs;
         s.nodes = nodes;
         s.uses_bvh = 1;
+    }
+    // Spill area of the per-lane traversal stacks (see TravStack): a 4-wide level pushes at most 3
+    // entries, the 4-wide tree is at most as high as the binary one; the top RTX_MAX_DEPTH entries
+    // hold the transparencies of a shadow-ray chain.
+    {
+        const uint32_t height = s.uses_bvh ? bs.max_depth : 0;
+        const uint32_t need = 3 * ((height + 1) / 2 + 1) + 4;
+        s.spill_entries = (need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0) + RTX_MAX_DEPTH;
+        s.spill_stride = ctx->num_cus * 8 * 256;
+        int* spill = nullptr;
+        TRY(dev_alloc(ctx, ctx->build_allocs, &spill, (size_t)s.spill_entries * s.spill_stride));
+        s.spill = spill;
     }
     bs.uses_bvh = s.uses_bvh;
     TRY_HIP(hipEventRecord(ev1, st));
@@ -650,8 +739,8 @@ int rtx_bvh_build(rtx_context* ctx) {
     cleanup();
 #undef TRY
 #undef TRY_HIP
-    if (s.uses_bvh && bs.max_depth > 120)
-        return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the largest traversal stack");
+    if (s.uses_bvh && bs.max_depth > 200)
+        return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows");
     ctx->build_stats = bs;
     ctx->built = true;
     return RTX_OK;

@@ -22,19 +22,23 @@
 // In BVH mode records are stored in Morton order (leaf ranges are contiguous);
 // in exhaustive mode in primitive-id order.
 //
-// BvhNode (64 B, four quads): one traversal step fetches both children's boxes.
-//   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)
-//   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
-//   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)
-//   q3 = (bits(left), bits(right), 0, 0)
-// child >= 0: index of another BvhNode; child < 0: ~child = (first << 3) | (count - 1),
+// BvhNode (64 B, four quads): a 4-wide node with quantised child boxes; one traversal
+// step covers two levels of the binary tree for one 64-byte fetch.
+//   a = (bits(origin.x), bits(origin.y), bits(origin.z), ex | ey<<8 | ez<<16 | n_children<<24)
+//       origin = lower corner of the node's box; e* = biased f32 exponent of the per-axis
+//       grid step (step = 2^(e-127)); n_children = 2..4, children are packed first
+//   b = (qlo_x[4], qlo_y[4], qlo_z[4], qhi_x[4])   one byte per child: plane = origin + q * step
+//   c = (qhi_y[4], qhi_z[4], ref[0], ref[1])
+//   d = (ref[2], ref[3], 0, 0)
+// qlo is rounded down and qhi up, so a child's quantised box contains its padded box.
+// ref >= 0: index of another BvhNode; ref < 0: ~ref = (first << 3) | (count - 1),
 // a leaf of `count` (1..8) consecutive PrimRecs starting at `first`.
 // ---------------------------------------------------------------------------
 struct PrimRec {
     float4 q0, q1, q2;
 };
 struct BvhNode {
-    float4 q0, q1, q2, q3;
+    uint4 a, b, c, d;
 };
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
@@ -70,12 +74,16 @@ struct DevScene {
     const DevLight* lights;     // [n_lights]
     // traversal-side arrays
     const PrimRec* recs;        // [n_prims]
-    const BvhNode* nodes;       // [n_prims - 1] (sparse: only non-collapsed nodes are valid)
+    const BvhNode* nodes;       // [n_prims - 1] indexed by binary-tree node; only even-depth, non-collapsed entries are used
     // Rays whose origin lies outside the cube |o - safe_c|_inf <= safe_r take the
     // exhaustive loop: the sphere padding of the BVH is only proven inside it.
     float safe_c[3];
     float safe_r;
     float pad_rel;              // relative padding constant of the box test
+    int* spill;                 // [spill_entries][spill_stride] overflow of the per-lane traversal stacks
+    uint32_t spill_stride;      // thread slots = largest traversal grid * 256
+    uint32_t spill_entries;
+    int32_t tune[4];            // traversal tuning: [0] idle lanes that trigger a refill, [1] phase-vote weight (1/16ths)
 };
 
 // Work queue of rays: three arrays of 16-/8-byte elements so that every access
@@ -120,7 +128,9 @@ struct rtx_context {
     int64_t opt_force_mode = 0;   // 0 auto, 1 exhaustive, 2 bvh
     int64_t opt_batch_pixels = 1 << 22;
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
-    int64_t opt_profile = 0;      // time traversal kernels separately (adds events)
+    int64_t opt_trace_variant = 0; // 0: one ray per lane, grid-stride; 1: persistent wavefronts with lane refill
+    uint32_t num_cus = 256;
+    int32_t opt_tune[4] = {20, 8, 8, 0};
 };
 
 // -- helpers shared by the translation units ---------------------------------
@@ -135,7 +145,6 @@ int rtx_fail(rtx_context* ctx, int status, const std::string& msg);
 // rtx_bvh.hip
 int rtx_bvh_build(rtx_context* ctx);
 // rtx_trace.hip
-int rtx_stack_for(uint32_t depth_needed);
 int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
                          int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);
 // rtx_shade.hip

@@ -69,23 +69,27 @@ RTX_HD uint8_t col_u8(float c) {  // `(c * 255.0) as u8` (material.rs:57-63): tr
 // Poly::intersects (src/scene/shapes/poly.rs:138-179) with e1 = v1 - v0 and
 // e2 = v2 - v0 taken from the primitive record (they are the same f32 values
 // the reference recomputes per call). Returns true and sets t on Hit.
+//
+// Written without early returns: a GPU lane gains nothing from leaving early
+// (its wavefront keeps going) and every `return` costs an exec-mask branch. The
+// arithmetic that produces t is the reference's, in the reference's order, and the
+// accept condition is the conjunction of the negated reject tests, which is what
+// the early-return chain evaluates (a NaN fails no reject test and then fails
+// `t > 1e-7`, exactly as in the chain).
 RTX_HD bool tri_intersect(V3 p, V3 d, V3 v0, V3 e1, V3 e2, float* t_out) {
-    V3 h = vcross(d, e2);
-    float a0 = vdot(e1, h);
-    if (a0 > -0.0000001f && a0 < 0.0000001f) return false;
-    float f = 1.0f / a0;
-    V3 s = p - v0;
-    float u = f * vdot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
-    V3 q = vcross(s, e1);
-    float v = f * vdot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float t = f * vdot(e2, q);
-    if (t > 0.0000001f) {
-        *t_out = t;
-        return true;
-    }
-    return false;
+    const V3 h = vcross(d, e2);
+    const float a0 = vdot(e1, h);
+    const float f = 1.0f / a0;
+    const V3 s = p - v0;
+    const float u = f * vdot(s, h);
+    const V3 q = vcross(s, e1);
+    const float v = f * vdot(d, q);
+    const float t = f * vdot(e2, q);
+    const bool parallel = a0 > -0.0000001f && a0 < 0.0000001f;
+    const bool out_u = u < 0.0f || u > 1.0f;
+    const bool out_v = v < 0.0f || u + v > 1.0f;
+    *t_out = t;
+    return !parallel && !out_u && !out_v && t > 0.0000001f;
 }
 
 // Sphere::intersects (src/scene/shapes/sphere.rs:54-103).

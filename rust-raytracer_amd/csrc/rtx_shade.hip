@@ -17,10 +17,8 @@
 #include <cstring>
 #include <utility>
 
+#include "rtx_persist.h"
 #include "rtx_shading.h"
-#include "rtx_traverse.h"
-
-int rtx_stack_for(uint32_t depth_needed);
 
 namespace {
 
@@ -29,7 +27,8 @@ struct Ctl {
     uint32_t n_nodes;
     uint32_t pool_base;
     uint32_t overflow;
-    uint32_t pad[3];
+    uint32_t work_head[2];   // dynamic work counters of the persistent traversal kernels (closest, shadow)
+    uint32_t pad[1];
     uint32_t level_start[RTX_MAX_DEPTH + 2];
     unsigned long long stat[7];    // primary, shadow, reflect, refract, skipped, nodes, panic
     unsigned long long saved[7];   // snapshot at batch start, restored when a batch is re-rendered
@@ -110,6 +109,7 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
         else ctl->saved[k] = ctl->stat[k];
     }
     ctl->overflow = 0;
+    ctl->work_head[0] = ctl->work_head[1] = 0;
     ctl->n_rays[0] = n;
     ctl->n_rays[1] = 0;
     ctl->n_nodes = 0;
@@ -137,20 +137,20 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(CamSetup cam, Work wk, uin
     }
 }
 
-// Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201).
-template <int STACK>
+// Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
+// one ray per lane, grid-stride over a grid that fits the device (variant 0, the default).
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue q, const uint32_t* __restrict__ n_ptr,
                                                            const uint32_t* __restrict__ overflow) {
-    __shared__ int lds[STACK * RTX_BLOCK];
-    LaneStack<STACK> st;
-    st.set(lds);
+    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    TravStack st;
+    st.set(lds, s);
     if (*overflow) return;   // the batch is being abandoned
     const uint32_t n = *n_ptr;
     for (uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += gridDim.x * RTX_BLOCK) {
         const float4 o4 = q.o[i], d4 = q.d[i];
         int id = -1;
         float t = 0.0f;
-        if (f2u(d4.w) & RTX_RAY_VALID) trace_closest<STACK>(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
+        if (f2u(d4.w) & RTX_RAY_VALID) trace_closest(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
         q.hit[i] = make_uint2((uint32_t)id, f2u(t));
     }
 }
@@ -227,86 +227,179 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
     }
 }
 
-// Forward step 2: RayTracer::shadow_scalar (lib.rs:105-141) for one (node, light)
+// Forward step 2: RayTracer::shadow_scalar (lib.rs:105-141), one (node, light) task
 // per lane, tasks ordered light-major so a wavefront's rays converge on one light.
-// ANY: scenes without transparent materials, first occluder ends the search.
-// otherwise: closest hit, continued through transparent hits up to `depth` times;
-// the chain's transparencies are parked in the top of the lane's LDS stack so the
+// ANY: scenes without transparent materials, the first occluder ends the search.
+// Otherwise: closest hit, continued through transparent hits up to `depth` times; the
+// chain's transparencies are parked in the top of the lane's spill column so that the
 // products can be formed innermost-first exactly as the recursion does.
-template <int STACK, bool ANY>
+struct ShadowTask {
+    const DevScene* s;
+    Work wk;
+    uint32_t nn, depth;
+    TravStack* st;
+    uint32_t j, node;    // current task
+    uint32_t rem;        // remaining recursion depth of shadow_scalar
+    int chain;           // transparent hits passed so far
+    unsigned long long rays;
+
+    RTX_D void store(float v) { wk.shadow[(size_t)j * wk.cap_rays + node] = v; }
+    RTX_D int* kt_slot(int k) { return st->spill + (size_t)(s->spill_entries - 1 - (uint32_t)k) * st->spill_stride; }
+    // Sets up the shadow ray of task `item`; false when the light is skipped (fattj <= 0, lib.rs:218).
+    RTX_D bool start(uint32_t item, V3& o, V3& d, float& dl) {
+        j = item / nn;
+        node = item - j * nn;
+        const DevLight light = s->lights[j];
+        const float4 p4 = wk.nP[node], n4 = wk.nN[node];
+        const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z);
+        if (!(calculate_fattj(light, point) > 0.0f)) {
+            store(0.0f);
+            return false;
+        }
+        o = point + vmult(normal, 0.0001f);                   // lib.rs:111
+        d = light_dir(light, o);
+        dl = (light.type == RTX_LIGHT_DIRECTIONAL) ? -1.0f : vdistance(o, light_pos(light));
+        rem = depth;
+        chain = 0;
+        ++rays;
+        return true;
+    }
+    RTX_D void finish_any(bool occluded) { store(clamp01((0.0f + (occluded ? 0.0f : 1.0f)) / 1.0f)); }
+    // Closest-hit form: (id, t) is the closest hit of the ray (o, d). True: continue with the new ray in o/d.
+    RTX_D bool finish_closest(int id, float t, V3& o, V3& d) {
+        const DevLight light = s->lights[j];
+        float term = 1.0f;
+        if (id >= 0) {
+            const HitGeom g = hit_geometry(*s, id, o, d, t, false);
+            const rtx_material* m = material_or_null(*s, g.mat0);
+            const float kt = m ? m->transparency : 0.0f;
+            if (kt == 0.0f) {
+                term = (light.type == RTX_LIGHT_DIRECTIONAL)
+                           ? 0.0f
+                           : ((vdistance(o, g.p) > vdistance(o, light_pos(light))) ? 1.0f : 0.0f);
+            } else {
+                *kt_slot(chain) = (int)f2u(kt);       // kt * shadow_scalar(hit, depth - 1)
+                ++chain;
+                --rem;
+                if (rem != 0) {
+                    o = g.p + vmult(g.n, 0.0001f);
+                    d = light_dir(light, o);
+                    ++rays;
+                    return true;
+                }
+                term = -1.0f;                         // depth exhausted: the innermost call returns Color::new()
+            }
+        }
+        float inner = (term < 0.0f) ? 0.0f : clamp01((0.0f + term) / 1.0f);
+        while (chain > 0) {                           // products innermost-first, as the recursion forms them
+            --chain;
+            inner = clamp01((0.0f + u2f((uint32_t)*kt_slot(chain)) * inner) / 1.0f);
+        }
+        store(inner);
+        return false;
+    }
+};
+
+template <bool ANY>
 __global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint32_t depth) {
-    __shared__ int lds[STACK * RTX_BLOCK];
-    LaneStack<STACK> st;
-    st.set(lds);
+    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    TravStack st;
+    st.set(lds, s);
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
-    const uint32_t nn = ctl->n_nodes;
-    const uint64_t total = (uint64_t)nn * s.n_lights;
-    const uint64_t stride = (uint64_t)gridDim.x * RTX_BLOCK;
-    unsigned long long rays = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * RTX_BLOCK; base < total; base += stride) {
-        const uint64_t k = base + threadIdx.x;
-        if (k < total) {
-            const uint32_t j = (uint32_t)(k / nn), node = (uint32_t)(k - (uint64_t)j * nn);
-            const DevLight light = s.lights[j];
-            const float4 p4 = wk.nP[node], n4 = wk.nN[node];
-            const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z);
-            float result = 0.0f;
-            const float fattj = calculate_fattj(light, point);   // lights with fattj <= 0 are skipped (lib.rs:218)
-            if (fattj > 0.0f) {
-                V3 ori = point + vmult(normal, 0.0001f);          // lib.rs:111
-                V3 dir = light_dir(light, ori);
-                const bool directional = light.type == RTX_LIGHT_DIRECTIONAL;
-                if (ANY) {
-                    const float dl = directional ? -1.0f : vdistance(ori, light_pos(light));
-                    ++rays;
-                    const float term = trace_any<STACK>(s, ori, dir, dl, st) ? 0.0f : 1.0f;
-                    result = clamp01((0.0f + term) / 1.0f);
-                } else {
-                    int chain = 0;
-                    uint32_t rem = depth;
-                    float inner;   // value returned by the innermost shadow_scalar call
-                    for (;;) {
-                        ++rays;
-                        float t;
-                        int id;
-                        trace_closest<STACK>(s, ori, dir, st, t, id);
-                        float term;
-                        if (id < 0) {
-                            term = 1.0f;
-                        } else {
-                            const HitGeom g = hit_geometry(s, id, ori, dir, t, false);
-                            const rtx_material* m = material_or_null(s, g.mat0);
-                            const float kt = m ? m->transparency : 0.0f;
-                            if (kt == 0.0f) {
-                                term = directional ? 0.0f
-                                                   : ((vdistance(ori, g.p) > vdistance(ori, light_pos(light))) ? 1.0f : 0.0f);
-                            } else {
-                                // kt * shadow_scalar(hit, depth - 1)
-                                st.put(STACK - 1 - chain, (int)f2u(kt));
-                                ++chain;
-                                --rem;
-                                if (rem == 0) { inner = 0.0f; break; }   // depth <= 0 -> Color::new()
-                                ori = g.p + vmult(g.n, 0.0001f);
-                                dir = light_dir(light, ori);
-                                continue;
-                            }
-                        }
-                        inner = clamp01((0.0f + term) / 1.0f);
-                        break;
-                    }
-                    while (chain > 0) {
-                        --chain;
-                        const float kt = u2f((uint32_t)st.get(STACK - 1 - chain));
-                        inner = clamp01((0.0f + kt * inner) / 1.0f);
-                    }
-                    result = inner;
-                }
+    ShadowTask task;
+    task.s = &s;
+    task.wk = wk;
+    task.nn = min(ctl->n_nodes, wk.cap_rays);
+    task.depth = depth;
+    task.st = &st;
+    task.rays = 0;
+    const uint64_t total = (uint64_t)task.nn * s.n_lights;
+    for (uint64_t k = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x; k < total; k += (uint64_t)gridDim.x * RTX_BLOCK) {
+        V3 o, d;
+        float dl;
+        if (!task.start((uint32_t)k, o, d, dl)) continue;
+        if (ANY) {
+            task.finish_any(trace_any(s, o, d, dl, st));
+        } else {
+            for (;;) {
+                float t;
+                int id;
+                trace_closest(s, o, d, st, t, id);
+                if (!task.finish_closest(id, t, o, d)) break;
             }
-            wk.shadow[(size_t)j * wk.cap_rays + node] = result;
         }
     }
-    // one atomic per wavefront
+    unsigned long long rays = task.rays;
+    for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
+}
+
+// ---- persistent-wavefront variants of the two traversal kernels (rtx_persist.h), variant 1 ----
+struct TraceJob {
+    RayQueue q;
+    uint32_t item;
+    RTX_D bool start(uint32_t i, V3& o, V3& d, float&) {
+        const float4 o4 = q.o[i], d4 = q.d[i];
+        if (!(f2u(d4.w) & RTX_RAY_VALID)) {
+            q.hit[i] = make_uint2(0xffffffffu, 0u);
+            return false;
+        }
+        item = i;
+        o = v3(o4.x, o4.y, o4.z);
+        d = v3(d4.x, d4.y, d4.z);
+        return true;
+    }
+    RTX_D bool finish(const Trav& tr, V3&, V3&, float&) {
+        const bool hit = tr.best_id != 0x7fffffff;
+        q.hit[item] = make_uint2(hit ? (uint32_t)tr.best_id : 0xffffffffu, f2u(hit ? tr.best_t : 0.0f));
+        return false;
+    }
+};
+
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_p(DevScene s, RayQueue q, Ctl* ctl, int qi, uint32_t first_dynamic) {
+    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    if (ctl->overflow) return;
+    TravStack st;
+    st.set(lds, s);
+    TraceJob job;
+    job.q = q;
+    persistent_trace<false>(s, job, st, ctl->n_rays[qi], &ctl->work_head[0], first_dynamic);
+}
+
+template <bool ANY>
+struct ShadowJob {
+    ShadowTask task;
+    RTX_D bool start(uint32_t item, V3& o, V3& d, float& dl) { return task.start(item, o, d, dl); }
+    RTX_D bool finish(const Trav& tr, V3& o, V3& d, float& dl) {
+        if (ANY) {
+            task.finish_any(tr.best_id != 0);
+            return false;
+        }
+        o = tr.o;
+        d = tr.d;
+        dl = -1.0f;
+        return task.finish_closest(tr.best_id == 0x7fffffff ? -1 : tr.best_id, tr.best_t, o, d);
+    }
+};
+
+template <bool ANY>
+__global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uint32_t depth, uint32_t first_dynamic) {
+    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    Ctl* ctl = wk.ctl;
+    if (ctl->overflow) return;
+    TravStack st;
+    st.set(lds, s);
+    ShadowJob<ANY> job;
+    job.task.s = &s;
+    job.task.wk = wk;
+    job.task.nn = min(ctl->n_nodes, wk.cap_rays);
+    job.task.depth = depth;
+    job.task.st = &st;
+    job.task.rays = 0;
+    const uint64_t total = (uint64_t)job.task.nn * s.n_lights;
+    persistent_trace<ANY>(s, job, st, (uint32_t)min(total, (uint64_t)0xfffffff0u), &ctl->work_head[1], first_dynamic);
+    unsigned long long rays = job.task.rays;
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
 }
@@ -383,6 +476,7 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
     ctl->pool_base += min(ctl->n_nodes, cap_rays);
     ctl->level_start[level + 1] = ctl->pool_base;
     ctl->n_nodes = 0;
+    ctl->work_head[0] = ctl->work_head[1] = 0;
     ctl->n_rays[q_consumed] = 0;
     if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
 }
@@ -513,22 +607,42 @@ struct EventPool {
     }
 };
 
-template <int STACK>
-void launch_trace(const DevScene& s, const RayQueue& q, const uint32_t* n_ptr, const uint32_t* overflow, uint32_t n_upper,
-                  hipStream_t st) {
-    hipLaunchKernelGGL(k_trace_queue<STACK>, dim3(blocks_for(n_upper, 1u << 20)), dim3(RTX_BLOCK), 0, st, s, q, n_ptr, overflow);
+// Every traversal launch is bounded by the spill area: at most blocks_per_cu * CUs workgroups.
+uint32_t trav_blocks(const rtx_context* ctx, uint64_t items) {
+    const uint64_t cap = (uint64_t)ctx->num_cus * (uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items + RTX_BLOCK - 1) / RTX_BLOCK, cap));
 }
-void dispatch_trace(int stack, const DevScene& s, const RayQueue& q, const uint32_t* n_ptr, const uint32_t* overflow,
-                    uint32_t n_upper, hipStream_t st) {
-    if (stack == 32) launch_trace<32>(s, q, n_ptr, overflow, n_upper, st);
-    else if (stack == 64) launch_trace<64>(s, q, n_ptr, overflow, n_upper, st);
-    else launch_trace<128>(s, q, n_ptr, overflow, n_upper, st);
+// Persistent launches: one chunk of kChunk items per wavefront is assigned statically (wave w
+// starts with chunk w); further chunks come from the atomic counter, offset by first_dynamic.
+struct PersistGrid {
+    uint32_t blocks, first_dynamic;
+};
+PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
+    const uint64_t chunks = (items_upper + kChunk - 1) / kChunk;
+    const uint32_t blocks = trav_blocks(ctx, ((chunks + 3) / 4) * RTX_BLOCK);
+    return PersistGrid{blocks, blocks * 4 * kChunk};
 }
-template <int STACK>
-void launch_shadow(const DevScene& s, const Work& wk, uint32_t depth, uint64_t tasks_upper, bool any, hipStream_t st) {
-    const dim3 grid(blocks_for(tasks_upper, 1u << 20));
-    if (any) hipLaunchKernelGGL((k_shadow<STACK, true>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
-    else hipLaunchKernelGGL((k_shadow<STACK, false>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, hipStream_t st) {
+    const DevScene& s = ctx->ds;
+    if (ctx->opt_trace_variant == 0) {
+        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], &wk.ctl->n_rays[qi],
+                           &wk.ctl->overflow);
+    } else {
+        const PersistGrid g = persist_grid(ctx, n_upper);
+        hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);
+    }
+}
+void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, bool any, hipStream_t st) {
+    const DevScene& s = ctx->ds;
+    if (ctx->opt_trace_variant == 0) {
+        const dim3 grid(trav_blocks(ctx, tasks_upper));
+        if (any) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+    } else {
+        const PersistGrid g = persist_grid(ctx, tasks_upper);
+        if (any) hipLaunchKernelGGL(k_shadow_p<true>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
+        else hipLaunchKernelGGL(k_shadow_p<false>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
+    }
 }
 
 }  // namespace
@@ -574,9 +688,6 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     // Without reflective or refractive materials no child is ever spawned: one level is exact.
     const uint32_t levels = ctx->has_secondary ? depth : std::min<uint32_t>(depth, 1);
     const bool any_shadow = !s.has_transparent;
-    const int stack_trace = rtx_stack_for(ctx->build_stats.max_depth + 1);
-    const int stack_shadow = rtx_stack_for(ctx->build_stats.max_depth + 1 + (any_shadow ? 0 : depth));
-
     EventPool ev{ctx};
     hipEvent_t f0 = ev.next(), f1 = ev.next();
     if (!f0 || !f1) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -595,12 +706,12 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         int qi = 0;
         uint32_t n_rays = n, levels_done = 0;
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
-            dispatch_trace(stack_trace, s, wk.q[0], &wk.ctl->n_rays[0], &wk.ctl->overflow, n_rays, st);
+            launch_closest(ctx, wk, 0, n_rays, st);
         for (uint32_t level = 0; level < levels; ++level) {
             hipEvent_t a = ev.next(), b = ev.next();
             if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
             RTX_HIP(ctx, hipEventRecord(a, st));
-            dispatch_trace(stack_trace, s, wk.q[qi], &wk.ctl->n_rays[qi], &wk.ctl->overflow, n_rays, st);
+            launch_closest(ctx, wk, qi, n_rays, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
@@ -609,9 +720,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
                 RTX_HIP(ctx, hipEventRecord(c, st));
                 const uint64_t tasks = (uint64_t)n_rays * s.n_lights;
-                if (stack_shadow == 32) launch_shadow<32>(s, wk, depth - level, tasks, any_shadow, st);
-                else if (stack_shadow == 64) launch_shadow<64>(s, wk, depth - level, tasks, any_shadow, st);
-                else launch_shadow<128>(s, wk, depth - level, tasks, any_shadow, st);
+                launch_shadow(ctx, wk, depth - level, tasks, any_shadow, st);
                 RTX_HIP(ctx, hipEventRecord(d, st));
                 shadow_events.emplace_back(c, d);
             }
@@ -682,7 +791,6 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
 }
 
 int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir) {
-    const DevScene& s = ctx->ds;
     hipStream_t st = ctx->stream;
     const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE, tiles_y = (h + RTX_TILE - 1) / RTX_TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
@@ -695,13 +803,12 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
     const CamSetup cam = make_cam(ctx->camera, w, h);
-    const int stack = rtx_stack_for(ctx->build_stats.max_depth + 1);
     for (uint64_t first = 0; first < rays; first += batch) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(batch, rays - first);
         hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0);
         hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, cam, wk, first, n, 0u, 1u, tiles_x,
                            (uint32_t)n_tiles);
-        dispatch_trace(stack, s, wk.q[0], &wk.ctl->n_rays[0], &wk.ctl->overflow, n, st);
+        launch_closest(ctx, wk, 0, n, st);
         hipLaunchKernelGGL(k_primary_out, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, wk.q[0], first, n, w, h, tiles_x,
                            d_prim, d_t, d_dir);
     }

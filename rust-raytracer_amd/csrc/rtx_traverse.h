@@ -49,8 +49,12 @@ RTX_D void trace_exhaustive(const DevScene& s, V3 o, V3 d, float& best_t, int& b
     if (best_id == 0x7fffffff) best_id = -1;
 }
 
-struct RayBox {  // per-ray constants of the slab test
-    V3 om, op;   // origin shifted by +pad / -pad
+// Per-ray constants of the slab test: (b - (o +- pad)) * inv is evaluated as
+// fma(b, inv, -(o +- pad) * inv), one operation per plane. The fused form differs
+// from the unfused one by a rounding of the box coordinate, far inside the padding;
+// only box tests are fused, primitive tests keep the reference's operation order.
+struct RayBox {
+    V3 oim, oip;   // (o + pad) * inv, (o - pad) * inv
     V3 inv;
 };
 RTX_D float safe_inv(float d) {
@@ -60,17 +64,17 @@ RTX_D RayBox make_raybox(const DevScene& s, V3 o, V3 d) {
     const float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
     const float pad = s.pad_rel * m;
     RayBox rb;
-    rb.om = v3(o.x + pad, o.y + pad, o.z + pad);
-    rb.op = v3(o.x - pad, o.y - pad, o.z - pad);
     rb.inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    rb.oim = v3((o.x + pad) * rb.inv.x, (o.y + pad) * rb.inv.y, (o.z + pad) * rb.inv.z);
+    rb.oip = v3((o.x - pad) * rb.inv.x, (o.y - pad) * rb.inv.y, (o.z - pad) * rb.inv.z);
     return rb;
 }
 // Conservative slab test; t_in is the entry parameter (can be negative).
 RTX_D bool box_hit(const RayBox& rb, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                    float best_t, float& t_in) {
-    const float ax = (bx0 - rb.om.x) * rb.inv.x, bx = (bx1 - rb.op.x) * rb.inv.x;
-    const float ay = (by0 - rb.om.y) * rb.inv.y, by = (by1 - rb.op.y) * rb.inv.y;
-    const float az = (bz0 - rb.om.z) * rb.inv.z, bz = (bz1 - rb.op.z) * rb.inv.z;
+    const float ax = __builtin_fmaf(bx0, rb.inv.x, -rb.oim.x), bx = __builtin_fmaf(bx1, rb.inv.x, -rb.oip.x);
+    const float ay = __builtin_fmaf(by0, rb.inv.y, -rb.oim.y), by = __builtin_fmaf(by1, rb.inv.y, -rb.oip.y);
+    const float az = __builtin_fmaf(bz0, rb.inv.z, -rb.oim.z), bz = __builtin_fmaf(bz1, rb.inv.z, -rb.oip.z);
     const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     t_in = lo;
@@ -82,21 +86,88 @@ RTX_D bool in_safe_region(const DevScene& s, V3 o) {
            fabsf(o.z - s.safe_c[2]) <= s.safe_r;  // false for NaN origins
 }
 
-// Per-lane traversal stack in LDS: entry k of lane l lives at stack[k * RTX_BLOCK + l],
-// so the lanes of a wavefront always touch 64 consecutive dwords (conflict-free
-// whatever their individual depths are).
-template <int STACK>
-struct LaneStack {
+// Per-lane traversal stack. The first RTX_STACK_LDS entries live in LDS: entry k of
+// lane l at lds[k * RTX_BLOCK + l], so the lanes of a wavefront always touch 64
+// consecutive dwords (conflict-free whatever their individual depths are). Deeper
+// entries, which near-first traversal rarely needs, spill to a global array laid out
+// the same way ([entry][thread slot]); keeping the LDS part at 16 KiB per workgroup is
+// what lets 8 workgroups (32 wavefronts) share a CU. The spill area has
+// DevScene::spill_stride thread slots, so traversal grids are bounded by it.
+#define RTX_STACK_LDS 16
+struct TravStack {
     int* base;
-    RTX_D void set(int* lds) { base = lds + threadIdx.x; }
-    RTX_D void put(int sp, int v) { base[sp * RTX_BLOCK] = v; }
-    RTX_D int get(int sp) const { return base[sp * RTX_BLOCK]; }
+    int* spill;
+    uint32_t spill_stride;
+    RTX_D void set(int* lds, const DevScene& s) {
+        base = lds + threadIdx.x;
+        spill = s.spill + (blockIdx.x * RTX_BLOCK + threadIdx.x);
+        spill_stride = s.spill_stride;
+    }
+    RTX_D void put(int sp, int v) {
+        if (sp < RTX_STACK_LDS) base[sp * RTX_BLOCK] = v;
+        else spill[(size_t)(sp - RTX_STACK_LDS) * spill_stride] = v;
+    }
+    RTX_D int get(int sp) const {
+        if (sp < RTX_STACK_LDS) return base[sp * RTX_BLOCK];
+        return spill[(size_t)(sp - RTX_STACK_LDS) * spill_stride];
+    }
 };
 
+// One step through a 4-wide node (layout: rtx_internal.h). The child boxes are
+// 8-bit offsets from the node's origin in units of a per-axis power of two, so the
+// slab test runs directly on the quantised values:
+//     t = fma(q, scale * inv, fma(origin, inv, -(o +- pad) * inv)).
+// The quantised boxes contain the padded boxes they were built from, so the test
+// stays conservative. Children that are hit are ordered near to far; the nearest
+// becomes the next node and the others are pushed, farthest first.
+// Returns the next reference, or `done` when nothing is hit and the stack is empty.
+RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& rb, float limit, TravStack& st, int& sp,
+                     int done) {
+    const uint4 A = nodes[cur].a, B = nodes[cur].b, C = nodes[cur].c, D = nodes[cur].d;
+    const uint32_t meta = A.w;
+    const float sx = u2f((meta & 0xffu) << 23) * rb.inv.x;
+    const float sy = u2f(((meta >> 8) & 0xffu) << 23) * rb.inv.y;
+    const float sz = u2f(((meta >> 16) & 0xffu) << 23) * rb.inv.z;
+    const uint32_t nchild = meta >> 24;
+    const float ox = u2f(A.x), oy = u2f(A.y), oz = u2f(A.z);
+    const float lx = __builtin_fmaf(ox, rb.inv.x, -rb.oim.x), hx = __builtin_fmaf(ox, rb.inv.x, -rb.oip.x);
+    const float ly = __builtin_fmaf(oy, rb.inv.y, -rb.oim.y), hy = __builtin_fmaf(oy, rb.inv.y, -rb.oip.y);
+    const float lz = __builtin_fmaf(oz, rb.inv.z, -rb.oim.z), hz = __builtin_fmaf(oz, rb.inv.z, -rb.oip.z);
+    const float inf = __builtin_inff();
+    float t[4];
+    int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 8 * k;
+        const float ax = __builtin_fmaf((float)((B.x >> sh) & 0xffu), sx, lx), bx = __builtin_fmaf((float)((B.w >> sh) & 0xffu), sx, hx);
+        const float ay = __builtin_fmaf((float)((B.y >> sh) & 0xffu), sy, ly), by = __builtin_fmaf((float)((C.x >> sh) & 0xffu), sy, hy);
+        const float az = __builtin_fmaf((float)((B.z >> sh) & 0xffu), sz, lz), bz = __builtin_fmaf((float)((C.y >> sh) & 0xffu), sz, hz);
+        const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const bool hit = ((uint32_t)k < nchild) && (lo <= hi) && (hi >= 0.0f) && (lo <= limit);
+        t[k] = hit ? lo : inf;
+    }
+#define RTX_CE(i, j)                                   \
+    do {                                               \
+        const bool sw = t[j] < t[i];                   \
+        const float ta = sw ? t[j] : t[i], tb = sw ? t[i] : t[j]; \
+        const int ra = sw ? r[j] : r[i], rb_ = sw ? r[i] : r[j];  \
+        t[i] = ta; t[j] = tb; r[i] = ra; r[j] = rb_;   \
+    } while (0)
+    RTX_CE(0, 1); RTX_CE(2, 3); RTX_CE(0, 2); RTX_CE(1, 3); RTX_CE(1, 2);
+#undef RTX_CE
+    if (t[3] < inf) st.put(sp++, r[3]);
+    if (t[2] < inf) st.put(sp++, r[2]);
+    if (t[1] < inf) st.put(sp++, r[1]);
+    if (t[0] < inf) return r[0];
+    if (sp == 0) return done;
+    return st.get(--sp);
+}
+
+constexpr int kRefDone = 0x7fffffff;   // "no more work" reference (never a node index: fewer than 2^28 nodes exist)
+
 // Closest hit through the BVH. Returns best_id = -1 on a miss.
-// `t_limit` bounds the search (inf for closest-hit queries).
-template <int STACK>
-RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, LaneStack<STACK>& st, float& best_t, int& best_id) {
+RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float& best_t, int& best_id) {
     if (!in_safe_region(s, o)) {
         trace_exhaustive(s, o, d, best_t, best_id);
         return;
@@ -104,31 +175,16 @@ RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, LaneStack<STACK>& st
     best_t = __builtin_inff();
     best_id = 0x7fffffff;
     const RayBox rb = make_raybox(s, o, d);
-    const BvhNode* __restrict__ nodes = s.nodes;
     int cur = 0, sp = 0;
-    for (;;) {
+    while (cur != kRefDone) {
         if (cur >= 0) {
-            const float4 q0 = nodes[cur].q0, q1 = nodes[cur].q1, q2 = nodes[cur].q2, q3 = nodes[cur].q3;
-            float tl, tr;
-            const bool hl = box_hit(rb, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tl);
-            const bool hr = box_hit(rb, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tr);
-            const int left = (int)f2u(q3.x), right = (int)f2u(q3.y);
-            if (hl && hr) {
-                const bool lnear = tl <= tr;
-                st.put(sp, lnear ? right : left);
-                sp = (sp + 1 < STACK) ? sp + 1 : sp;  // depth is checked on the host; never overflows
-                cur = lnear ? left : right;
-                continue;
-            }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
+            cur = node4_step(s.nodes, cur, rb, best_t, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
+            cur = (sp == 0) ? kRefDone : st.get(--sp);
         }
-        if (sp == 0) break;
-        cur = st.get(--sp);
     }
     if (best_id == 0x7fffffff) best_id = -1;
 }
@@ -158,8 +214,7 @@ RTX_D bool any_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d
     }
     return hit && occluding_hit(o, d, t, dist_light);
 }
-template <int STACK>
-RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, LaneStack<STACK>& st) {
+RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack& st) {
     if (!s.uses_bvh || !in_safe_region(s, o)) {
         for (uint32_t i = 0; i < s.n_prims; ++i)
             if (any_record(s.recs, i, o, d, dist_light)) return true;
@@ -175,38 +230,23 @@ RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, LaneStack<
         t_limit = (len > 0.0f) ? ((dist_light + 4e-6f * m) / len) * 1.0001f + 1e-6f : __builtin_inff();
     }
     const RayBox rb = make_raybox(s, o, d);
-    const BvhNode* __restrict__ nodes = s.nodes;
     int cur = 0, sp = 0;
-    for (;;) {
+    while (cur != kRefDone) {
         if (cur >= 0) {
-            const float4 q0 = nodes[cur].q0, q1 = nodes[cur].q1, q2 = nodes[cur].q2, q3 = nodes[cur].q3;
-            float tl, tr;
-            const bool hl = box_hit(rb, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, t_limit, tl);
-            const bool hr = box_hit(rb, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, t_limit, tr);
-            const int left = (int)f2u(q3.x), right = (int)f2u(q3.y);
-            if (hl && hr) {
-                st.put(sp, right);
-                sp = (sp + 1 < STACK) ? sp + 1 : sp;
-                cur = left;
-                continue;
-            }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
+            cur = node4_step(s.nodes, cur, rb, t_limit, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k)
                 if (any_record(s.recs, first + k, o, d, dist_light)) return true;
+            cur = (sp == 0) ? kRefDone : st.get(--sp);
         }
-        if (sp == 0) break;
-        cur = st.get(--sp);
     }
     return false;
 }
 
 // Closest hit in either mode.
-template <int STACK>
-RTX_D void trace_closest(const DevScene& s, V3 o, V3 d, LaneStack<STACK>& st, float& best_t, int& best_id) {
-    if (s.uses_bvh) trace_bvh_closest<STACK>(s, o, d, st, best_t, best_id);
+RTX_D void trace_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float& best_t, int& best_id) {
+    if (s.uses_bvh) trace_bvh_closest(s, o, d, st, best_t, best_id);
     else trace_exhaustive(s, o, d, best_t, best_id);
 }

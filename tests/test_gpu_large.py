@@ -35,7 +35,8 @@ def test_bvh_stats_1m(big):
     b = ctx.build_stats
     assert b["uses_bvh"] == 1 and b["n_prims"] == 1002528
     assert 0 < b["max_depth"] < 64
-    assert b["n_leaves"] == b["n_nodes"] + 1
+    # 4-wide nodes with 2..4 children: a tree with L leaves has between (L-1)/3 and L-1 inner nodes
+    assert (b["n_leaves"] - 1) / 3 <= b["n_nodes"] <= b["n_leaves"] - 1
 
 
 def test_1m_bvh_equals_exhaustive_on_camera_rays(big):
