@@ -89,6 +89,8 @@ def main():
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
         ctx.set_option("tune%d" % i, int(v))
     ctx.set_scene(flat)
+    for i, v in enumerate([x for x in args.tune.split(",") if x]):
+        ctx.set_option("tune%d" % i, int(v))
     build = ctx.build()
     w, h = args.width, args.height
     tpr = rtx.tiles_per_rank(w, h, world)
@@ -178,6 +180,8 @@ def main():
             "device_frame_ms_rank0": acc["render_ms"] / args.steps,
             "build_ms": build["build_ms"], "upload_ms": build["upload_ms"], "scene_broadcast_ms": bcast_ms,
             "bvh": {k: build[k] for k in ("n_nodes", "n_leaves", "max_depth", "key_bits", "uses_bvh")},
+            "kernels": {"closest_ms": acc["closest_ms"] / max(acc["closest_launches"], 1),
+                        "shadow_ms": acc["shadow_ms"] / max(acc["shadow_launches"], 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray},

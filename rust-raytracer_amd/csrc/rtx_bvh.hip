@@ -3,7 +3,7 @@
 //   bounds (Shape::get_bbox: poly.rs:122-136, sphere.rs:45-52; centroid: shapes/mod.rs:40-42)
 //   -> Morton keys -> LSD radix sort staged through LDS -> Karras hierarchy
 //   -> bottom-up refit (one launch per tree level) -> 64-byte traversal nodes
-//   with small subtrees collapsed into leaves of up to RTX_LEAF_MAX primitives.
+//   with small subtrees collapsed into leaves of a few primitives (tune3, default RTX_LEAF_MAX).
 // Queries on the result return what the exhaustive loop returns (see
 // rtx_traverse.h); the reference BVH's own tie rule (bvh.rs:134) is not copied.
 #include <algorithm>
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
                                                           float4* __restrict__ nmin, float4* __restrict__ nmax,
                                                           const int* __restrict__ parent, uint32_t* __restrict__ counter,
                                                           uint8_t* __restrict__ theight, int* __restrict__ qout,
-                                                          uint32_t* __restrict__ qout_count) {
+                                                          uint32_t* __restrict__ qout_count, int leaf_max) {
     const uint32_t cnt = *qin_count;
     for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += gridDim.x * kThreads) {
         const int i = qin[k];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
         nmin[i] = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), 0.0f);  // BoundingBox + , shapes/mod.rs:86-104
         nmax[i] = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
         const int size = rng_last[i] - rng_first[i] + 1;
-        const int h = (size <= RTX_LEAF_MAX) ? 0 : 1 + max((int)theight[l], (int)theight[r]);
+        const int h = (size <= leaf_max) ? 0 : 1 + max((int)theight[l], (int)theight[r]);
         theight[i] = (uint8_t)min(h, 255);
         const int p = parent[i];
         if (p >= 0 && atomicAdd(&counter[p], 1u) == 1u) qout[atomicAdd(qout_count, 1u)] = p;
@@ -393,18 +393,19 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
 }
 
 // Reference to binary node c as a child of a traversal node: a leaf (single primitive
-// or a collapsed subtree of at most RTX_LEAF_MAX primitives) or an inner node.
-__device__ __forceinline__ bool is_expandable(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last) {
-    return c < n - 1 && (rng_last[c] - rng_first[c] + 1) > RTX_LEAF_MAX;
+// or a collapsed subtree of at most leaf_max primitives) or an inner node.
+__device__ __forceinline__ bool is_expandable(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
+                                              int leaf_max) {
+    return c < n - 1 && (rng_last[c] - rng_first[c] + 1) > leaf_max;
 }
 __device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
-                                         uint32_t* leaf_count) {
+                                         uint32_t* leaf_count, int leaf_max) {
     if (c >= n - 1) {
         ++*leaf_count;
         return (int)~(((uint32_t)(c - (n - 1)) << 3) | 0u);
     }
     const int size = rng_last[c] - rng_first[c] + 1;
-    if (size <= RTX_LEAF_MAX) {
+    if (size <= leaf_max) {
         ++*leaf_count;
         return (int)~(((uint32_t)rng_first[c] << 3) | (uint32_t)(size - 1));
     }
@@ -428,13 +429,13 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
                                                      const int* __restrict__ parent, const int* __restrict__ rng_first,
                                                      const int* __restrict__ rng_last, const float4* __restrict__ nmin,
                                                      const float4* __restrict__ nmax, BvhNode* __restrict__ nodes,
-                                                     uint32_t* __restrict__ counts) {
+                                                     uint32_t* __restrict__ counts, int leaf_max) {
     __shared__ uint32_t s_nodes, s_leaves;
     if (threadIdx.x == 0) s_nodes = s_leaves = 0;
     __syncthreads();
     const int i = blockIdx.x * kThreads + threadIdx.x;
     uint32_t my_nodes = 0, my_leaves = 0;
-    bool emit = i < n - 1 && (rng_last[i] - rng_first[i] + 1) > RTX_LEAF_MAX;
+    bool emit = i < n - 1 && (rng_last[i] - rng_first[i] + 1) > leaf_max;
     if (emit) {
         int depth = 0;
         for (int p = parent[i]; p >= 0; p = parent[p]) ++depth;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int c = lr[k];
-            if (is_expandable(c, n, rng_first, rng_last)) {
+            if (is_expandable(c, n, rng_first, rng_last, leaf_max)) {
                 ch[nc++] = child_l[c];
                 ch[nc++] = child_r[c];
             } else {
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
             }
         }
         int ref[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nc; ++k) ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves);
+        for (int k = 0; k < nc; ++k) ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves, leaf_max);
         BvhNode nd;
         nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
                           eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24));
@@ -614,7 +615,8 @@ int rtx_bvh_build(rtx_context* ctx) {
     const float dmax = 1.7320508f * (s.safe_r + radius);   // farthest origin-to-centre distance inside the safe cube
     pp.sphere_k = (1.0f / 524288.0f) * dmax * dmax;        // 2^-19 * D^2, ~32 roundings of |o - c|^2
 
-    const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > RTX_LEAF_MAX)
+    const int leaf_max = std::min<int>(std::max<int>(ctx->opt_tune[3], 1), 8);
+    const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > (uint32_t)leaf_max)
                         : (ctx->opt_force_mode == 1) ? false : (n > RTX_EXHAUSTIVE_MAX);
     if (!want_bvh) {
         if (n > 0) hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, (const uint32_t*)nullptr, recs);
@@ -628,10 +630,17 @@ int rtx_bvh_build(rtx_context* ctx) {
         bs.key_bits = 3 * bits;
         MortonParams mp;
         mp.qmax = (float)((1u << bits) - 1u);
+        // One cell size for all three axes (the largest centroid extent spans the grid), so
+        // cells are cubes: a thin scene such as a height field is not stretched along its
+        // thin axis, which would interleave splits that separate nothing a ray cares about.
+        float max_ext = 0.0f;
         for (int k = 0; k < 3; ++k) {
             const float ext = cmax[k] - cmin[k];
+            if (std::isfinite(ext) && ext > max_ext) max_ext = ext;
+        }
+        for (int k = 0; k < 3; ++k) {
             mp.cmin[k] = cmin[k];
-            mp.scale[k] = (ext > 0.0f && std::isfinite(ext)) ? (float)(1u << bits) / ext : 0.0f;
+            mp.scale[k] = (max_ext > 0.0f) ? (float)(1u << bits) / max_ext : 0.0f;
         }
         uint64_t* keys[2];
         uint32_t* vals[2];
@@ -693,14 +702,14 @@ int rtx_bvh_build(rtx_context* ctx) {
             if (++levels > 4096) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
             TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
             hipLaunchKernelGGL(k_refit_pass, dim3(grid_for(cnt)), dim3(kThreads), 0, st, queue[q], &qcount[q], child_l, child_r,
-                               rng_first, rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1]);
+                               rng_first, rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1], leaf_max);
             q ^= 1;
         }
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
         TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
         hipLaunchKernelGGL(k_emit4, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, child_l, child_r,
-                           parent, rng_first, rng_last, nmin, nmax, nodes, counts);
+                           parent, rng_first, rng_last, nmin, nmax, nodes, counts, leaf_max);
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
         uint32_t hcounts[2] = {0, 0};
         uint8_t root_h = 0;

@@ -43,7 +43,7 @@ struct BvhNode {
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
-#define RTX_LEAF_MAX 4          // primitives per collapsed leaf (<= 8)
+#define RTX_LEAF_MAX 1          // default primitives per leaf (tune3, 1..8): triangle fetches cost more than child boxes
 #define RTX_EXHAUSTIVE_MAX 16   // scenes with at most this many primitives skip the BVH
 #define RTX_TILE 8              // primary rays are generated in 8x8-pixel tiles (one wavefront)
 
@@ -130,7 +130,7 @@ struct rtx_context {
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     int64_t opt_trace_variant = 0; // 0: one ray per lane, grid-stride; 1: persistent wavefronts with lane refill
     uint32_t num_cus = 256;
-    int32_t opt_tune[4] = {20, 8, 8, 0};
+    int32_t opt_tune[4] = {20, 8, 6, RTX_LEAF_MAX};
 };
 
 // -- helpers shared by the translation units ---------------------------------

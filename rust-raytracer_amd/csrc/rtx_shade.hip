@@ -29,6 +29,7 @@ struct Ctl {
     uint32_t overflow;
     uint32_t work_head[2];   // dynamic work counters of the persistent traversal kernels (closest, shadow)
     uint32_t pad[1];
+    uint32_t unit_head[2][8][32];   // per-shard work counters (closest, shadow), one 128-byte line each
     uint32_t level_start[RTX_MAX_DEPTH + 2];
     unsigned long long stat[7];    // primary, shadow, reflect, refract, skipped, nodes, panic
     unsigned long long saved[7];   // snapshot at batch start, restored when a batch is re-rendered
@@ -110,6 +111,7 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
     }
     ctl->overflow = 0;
     ctl->work_head[0] = ctl->work_head[1] = 0;
+    for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[0] = n;
     ctl->n_rays[1] = 0;
     ctl->n_nodes = 0;
@@ -137,16 +139,54 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(CamSetup cam, Work wk, uin
     }
 }
 
+// Dynamic distribution of work in units of 64 items (one wavefront's worth). The grid
+// is sized to the device, and a wavefront that finishes its unit takes the next one, so
+// wavefronts with cheap rays do not idle while others work through expensive ones. The
+// unit range is cut into 8 shards with one counter each (its own 128-byte line); a
+// workgroup starts on shard blockIdx % 8 -- workgroups b and b+8 usually share an XCD, so
+// a shard's rays stay in one L2 -- and moves on to the other shards when it runs dry.
+// One word would serve only ~90 atomics per microsecond; eight shards do not limit a launch.
+struct UnitQueue {
+    uint32_t* heads;        // [8][32]
+    uint32_t n_units, per_shard, shard, probe;
+    RTX_D void init(uint32_t* h, uint64_t n_items) {
+        heads = h;
+        n_units = (uint32_t)((n_items + 63) >> 6);
+        per_shard = (n_units + 7) >> 3;
+        shard = blockIdx.x & 7u;
+        probe = 0;
+    }
+    // Wave-uniform: next unit for this wavefront, or 0xffffffff when every shard is empty.
+    RTX_D uint32_t next() {
+        uint32_t unit = 0xffffffffu;
+        if ((threadIdx.x & 63) == 0) {
+            while (probe < 8) {
+                const uint32_t sh = (shard + probe) & 7u;
+                const uint32_t lo = sh * per_shard, hi = min(lo + per_shard, n_units);
+                if (lo < hi) {
+                    const uint32_t u = lo + atomicAdd(&heads[sh * 32], 1u);
+                    if (u < hi) { unit = u; break; }
+                }
+                ++probe;
+            }
+        }
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    }
+};
+
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
-// one ray per lane, grid-stride over a grid that fits the device (variant 0, the default).
-__global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue q, const uint32_t* __restrict__ n_ptr,
-                                                           const uint32_t* __restrict__ overflow) {
+// one ray per lane (variant 0, the default).
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     TravStack st;
     st.set(lds, s);
-    if (*overflow) return;   // the batch is being abandoned
-    const uint32_t n = *n_ptr;
-    for (uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += gridDim.x * RTX_BLOCK) {
+    if (ctl->overflow) return;   // the batch is being abandoned
+    const uint32_t n = ctl->n_rays[qi];
+    UnitQueue uq;
+    uq.init(&ctl->unit_head[0][0][0], n);
+    for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        const uint32_t i = unit * 64 + (threadIdx.x & 63);
+        if (i >= n) continue;
         const float4 o4 = q.o[i], d4 = q.d[i];
         int id = -1;
         float t = 0.0f;
@@ -314,8 +354,12 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint3
     task.depth = depth;
     task.st = &st;
     task.rays = 0;
-    const uint64_t total = (uint64_t)task.nn * s.n_lights;
-    for (uint64_t k = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x; k < total; k += (uint64_t)gridDim.x * RTX_BLOCK) {
+    const uint64_t total = min((uint64_t)task.nn * s.n_lights, (uint64_t)0xfffffff0u);
+    UnitQueue uq;
+    uq.init(&ctl->unit_head[1][0][0], total);
+    for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        const uint64_t k = (uint64_t)unit * 64 + (threadIdx.x & 63);
+        if (k >= total) continue;
         V3 o, d;
         float dl;
         if (!task.start((uint32_t)k, o, d, dl)) continue;
@@ -477,6 +521,7 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
     ctl->level_start[level + 1] = ctl->pool_base;
     ctl->n_nodes = 0;
     ctl->work_head[0] = ctl->work_head[1] = 0;
+    for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[q_consumed] = 0;
     if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
 }
@@ -625,8 +670,7 @@ PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, hipStream_t st) {
     const DevScene& s = ctx->ds;
     if (ctx->opt_trace_variant == 0) {
-        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], &wk.ctl->n_rays[qi],
-                           &wk.ctl->overflow);
+        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi);
     } else {
         const PersistGrid g = persist_grid(ctx, n_upper);
         hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);

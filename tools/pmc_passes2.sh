@@ -1,6 +1,12 @@
+# PMC passes over bench.py; each pass is its own rocprofv3 run (counters only, no API tracing).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V=${1:-1}
-run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc2_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --variant $V > $R/gpurun_out/pmc2_$name.log 2>&1; echo "$name rc=$?"; }
-run ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY && \
-run tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_IFETCH SQ_WAVE_CYCLES
+TAG=${1:-x}; shift
+ARGS="$@"
+run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $ARGS > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; echo "$name rc=$?"; }
+run sq1 SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD && \
+run sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS && \
+run ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY && \
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum && \
+run fetch FETCH_SIZE && \
+run write WRITE_SIZE
