@@ -99,10 +99,11 @@ def main():
     image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
 
     def step():
+        if world == 1:   # single GPU: the frame is written row-major in place
+            return ctx.render_device(w, h, args.depth, 10, image.data_ptr())
         st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slab.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, slab)
-            torch.cuda.current_stream().synchronize()
+        dist.all_gather_into_tensor(gathered, slab)
+        torch.cuda.current_stream().synchronize()
         ctx.assemble_tiles(w, h, world, gathered.data_ptr(), image.data_ptr())
         return st
 

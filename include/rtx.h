@@ -196,6 +196,10 @@ int rtx_primary_hits(rtx_context* ctx, uint32_t width, uint32_t height,
 int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
                uint8_t* rgb, rtx_render_stats* stats);
 
+/* Same frame, left on the device: d_rgb is DEVICE memory, [h][w][3] u8 row-major. */
+int rtx_render_device(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+                      uint8_t* d_rgb, rtx_render_stats* stats);
+
 /* Tile-sharded frame for one process per GPU. The image is cut into 8x8-pixel
  * tiles numbered row-major; this call renders tiles with
  * (tile_index % world) == rank. d_rgb_tiles is DEVICE memory receiving the

@@ -33,7 +33,7 @@ TILE = 8
 EXPORTED_SYMBOLS = [
     "rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
-    "rtx_render", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
+    "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
 ]
 
 
@@ -138,6 +138,7 @@ def lib():
         L.rtx_intersect_batch_exhaustive.argtypes = [vp, u64, vp, vp, vp, vp]
         L.rtx_primary_hits.argtypes = [vp, u32, u32, vp, vp, vp]
         L.rtx_render.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(RenderStats)]
+        L.rtx_render_device.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(RenderStats)]
         L.rtx_render_tiles.argtypes = [vp, u32, u32, u32, u32, u32, u32, vp, C.POINTER(RenderStats)]
         L.rtx_tiles_per_rank.argtypes = [u32, u32, u32]
         L.rtx_tiles_per_rank.restype = u64
@@ -349,6 +350,12 @@ class Context:
         st = RenderStats()
         self._check(self._L.rtx_render(self._h, width, height, depth, samples, _ptr(rgb), C.byref(st)))
         return rgb, st
+
+    def render_device(self, width, height, depth, samples, d_rgb):
+        """d_rgb: device pointer (int) to height * width * 3 bytes, row-major."""
+        st = RenderStats()
+        self._check(self._L.rtx_render_device(self._h, width, height, depth, samples, d_rgb, C.byref(st)))
+        return st
 
     def render_tiles(self, width, height, depth, samples, rank, world, d_rgb_tiles):
         """d_rgb_tiles: device pointer (int) to tiles_per_rank(width, height, world) * 192 bytes."""

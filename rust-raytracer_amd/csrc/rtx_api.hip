@@ -93,6 +93,7 @@ void rtx_destroy(rtx_context* ctx) {
     free_list(ctx->build_allocs);
     free_list(ctx->work_allocs);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -304,7 +305,7 @@ int rtx_render_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t
     if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
     if (world == 0 || rank >= world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rank must be below world");
     if (!d_rgb_tiles) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb_tiles is NULL");
-    return rtx_render_impl(ctx, width, height, depth, samples, rank, world, d_rgb_tiles, stats);
+    return rtx_render_impl(ctx, width, height, depth, samples, rank, world, d_rgb_tiles, stats, false);
 }
 
 int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb) {
@@ -317,21 +318,26 @@ int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32
     return RTX_OK;
 }
 
+int rtx_render_device(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* d_rgb,
+                      rtx_render_stats* stats) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (!d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb is NULL");
+    return rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_rgb, stats, true);
+}
+
 int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* rgb,
                rtx_render_stats* stats) {
     int rc = check_ready(ctx);
     if (rc != RTX_OK) return rc;
     if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
     if (!rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rgb is NULL");
-    const size_t slab = (size_t)rtx_tiles_per_rank(width, height, 1) * 64 * 3;
     const size_t img = (size_t)width * height * 3;
     Scratch sc;
-    uint8_t* d_tiles = sc.get<uint8_t>(slab);
     uint8_t* d_img = sc.get<uint8_t>(img);
-    if (!d_tiles || !d_img) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(framebuffer) failed");
-    rc = rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_tiles, stats);
-    if (rc != RTX_OK) return rc;
-    rc = rtx_assemble_impl(ctx, width, height, 1, d_tiles, d_img);
+    if (!d_img) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(framebuffer) failed");
+    rc = rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_img, stats, true);
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemcpyAsync(rgb, d_img, img, hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -122,6 +122,7 @@ struct rtx_context {
 
     std::vector<char> work_blob;  // the Work struct of rtx_shade.hip describing work_allocs
     std::vector<hipEvent_t> events;
+    void* pinned = nullptr;       // page-locked staging for counter read-backs
     bool has_secondary = false;   // some material reflects or refracts (src/lib.rs:230,241)
 
     // knobs (rtx_set_option)
@@ -149,6 +150,6 @@ int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, cons
                          int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);
 // rtx_shade.hip
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
-                    uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats);
+                    uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct);
 int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir);
 int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb);

@@ -529,7 +529,14 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
 // Backward: `direct + ambient + reflective + refractive` (lib.rs:254) with
 // reflective = ks * child (lib.rs:234) and refractive = child.mult(kt) (lib.rs:244-245).
 // A missing child left its slot at zero, which yields the same value as Color::new().
-__global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint32_t level, uint8_t* __restrict__ rgb) {
+// Where level-0 colours go: the rank's packed tile slab (pixel slot = ray index) or, for a
+// single-GPU frame, straight into the row-major image.
+struct OutMap {
+    uint8_t* rgb;
+    uint32_t direct_w;   // 0: tile slab; otherwise the image width (row-major output)
+    uint32_t tiles_x;
+};
+__global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint32_t level, OutMap out) {
     const Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     const uint32_t lo = ctl->level_start[level], hi = ctl->level_start[level + 1];
@@ -543,7 +550,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint
         const Col c = (Col{l4.x, l4.y, l4.z} + reflective) + refractive;
         const uint32_t link = wk.pLink[slot];
         if (level == 0) {
-            uint8_t* px = rgb + (size_t)link * 3;   // Color::as_pixel, material.rs:57-63
+            size_t pixel = link;
+            if (out.direct_w) {
+                const uint32_t tile = link >> 6, lane = link & 63u;
+                const uint32_t x = (tile % out.tiles_x) * RTX_TILE + (lane & 7u), y = (tile / out.tiles_x) * RTX_TILE + (lane >> 3);
+                pixel = (size_t)y * out.direct_w + x;
+            }
+            uint8_t* px = out.rgb + pixel * 3;   // Color::as_pixel, material.rs:57-63
             px[0] = col_u8(c.r);
             px[1] = col_u8(c.g);
             px[2] = col_u8(c.b);
@@ -698,7 +711,7 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
 }
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
-                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats) {
+                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct) {
     (void)samples;   // num_samples only multiplies area-light rays (lib.rs:219-222)
     const DevScene& s = ctx->ds;
     hipStream_t st = ctx->stream;
@@ -719,7 +732,18 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             primary += (uint64_t)tw * th;
         }
     }
-    RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, tiles_per_rank * 64 * 3, st));
+    // direct: d_rgb_tiles is a row-major [h][w][3] image (single GPU only); otherwise the rank's tile slab
+    if (direct && world != 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "row-major output needs world == 1");
+    RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
+    const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x};
+    if (!ctx->pinned) {
+        void* p = nullptr;
+        RTX_HIP(ctx, hipHostMalloc(&p, 8192, hipHostMallocDefault));
+        ctx->pinned = p;
+    }
+    Ctl* host_ctl = (Ctl*)ctx->pinned;
+    uint32_t* host_next = (uint32_t*)((char*)ctx->pinned + 4096);
+    static_assert(sizeof(Ctl) <= 4096, "Ctl must fit the pinned staging area");
 
     uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays_local, 64));
     batch = (batch + 63) & ~63ull;
@@ -772,9 +796,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
             levels_done = level + 1;
             if (level + 1 < levels) {
-                uint32_t next = 0;
-                RTX_HIP(ctx, hipMemcpyAsync(&next, &wk.ctl->n_rays[qi ^ 1], 4, hipMemcpyDeviceToHost, st));
+                RTX_HIP(ctx, hipMemcpyAsync(host_next, &wk.ctl->n_rays[qi ^ 1], 4, hipMemcpyDeviceToHost, st));
                 RTX_HIP(ctx, hipStreamSynchronize(st));
+                const uint32_t next = *host_next;
                 if (next == 0) break;
                 n_rays = std::min(next, wk.cap_rays);
                 qi ^= 1;
@@ -782,12 +806,15 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         }
         for (uint32_t level = levels_done; level-- > 0;) {
             const uint64_t upper = (level == 0) ? n : wk.cap_rays;
-            hipLaunchKernelGGL(k_combine, dim3(blocks_for(upper, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, level, d_rgb_tiles);
+            hipLaunchKernelGGL(k_combine, dim3(blocks_for(upper, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, level, out_map);
         }
-        uint32_t overflow = 0;
-        RTX_HIP(ctx, hipMemcpyAsync(&overflow, &wk.ctl->overflow, 4, hipMemcpyDeviceToHost, st));
+        // one read-back and one synchronisation per batch: counters, overflow flag (and, after
+        // the last batch, the frame-end event)
+        const bool last_batch = first + n >= rays_local;
+        RTX_HIP(ctx, hipMemcpyAsync(host_ctl, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+        if (last_batch) RTX_HIP(ctx, hipEventRecord(f1, st));
         RTX_HIP(ctx, hipStreamSynchronize(st));
-        if (overflow) {
+        if (host_ctl->overflow) {
             // The ray tree of this batch outgrew the queues: render the same pixels again in
             // smaller batches (the workspace keeps its size, so relative capacity doubles).
             if (cur_batch <= 64)
@@ -798,12 +825,14 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         }
         first += n;
     }
-    RTX_HIP(ctx, hipEventRecord(f1, st));
-    RTX_HIP(ctx, hipEventSynchronize(f1));
+    if (rays_local == 0) {
+        RTX_HIP(ctx, hipEventRecord(f1, st));
+        RTX_HIP(ctx, hipStreamSynchronize(st));
+        std::memset(host_ctl, 0, sizeof(Ctl));
+    }
     RTX_HIP(ctx, hipGetLastError());
     if (stats) {
-        Ctl hc;
-        RTX_HIP(ctx, hipMemcpy(&hc, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+        const Ctl& hc = *host_ctl;   // read back with the last batch
         rtx_render_stats rs{};
         rs.primary_rays = primary;
         rs.shadow_rays = hc.stat[ST_SHADOW];
