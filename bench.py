@@ -157,7 +157,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("bytes_per_launch")
+                    traffic = json.load(f)["kernels"]["shadow" if kname.startswith("k_shadow") else "closest"]["bytes_per_launch"]
             except Exception:
                 traffic = None
         out = {
