@@ -200,7 +200,8 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
             l.b[k] = d->lights[i].b[k];
             l.color[k] = clamp01(d->lights[i].color[k]);   // Color::init clamps (parser/mod.rs:111-114)
         }
-        if (l.type == RTX_LIGHT_AREA) s.has_area_light = 1;
+        l.area_before = s.n_area_lights;   // counts the area lights seen so far
+        if (l.type == RTX_LIGHT_AREA) ++s.n_area_lights;
         lights[i] = l;
     }
     S_TRY(upload(ctx, lights.data(), lights.size(), &d_lights));

@@ -725,12 +725,12 @@ int rtx_bvh_build(rtx_context* ctx) {
         s.uses_bvh = 1;
     }
     // Spill area of the per-lane traversal stacks (see TravStack): a 4-wide level pushes at most 3
-    // entries, the 4-wide tree is at most as high as the binary one; the top RTX_MAX_DEPTH entries
-    // hold the transparencies of a shadow-ray chain.
+    // entries, the 4-wide tree is at most as high as the binary one; with transparent materials the
+    // top 8 * RTX_MAX_DEPTH entries hold the suspended calls of a shadow ray's recursion.
     {
         const uint32_t height = s.uses_bvh ? bs.max_depth : 0;
         const uint32_t need = 3 * ((height + 1) / 2 + 1) + 4;
-        s.spill_entries = (need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0) + RTX_MAX_DEPTH;
+        s.spill_entries = (need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0) + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
         s.spill_stride = ctx->num_cus * 8 * 256;
         int* spill = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &spill, (size_t)s.spill_entries * s.spill_stride));

@@ -51,7 +51,7 @@ struct DevLight {  // 48 B
     float a[3];
     uint32_t type;
     float b[3];
-    float pad0;
+    uint32_t area_before;   // number of area lights with a smaller index (shadow-term slots, see Work::shadow)
     float color[3];
     float pad1;
 };
@@ -61,7 +61,7 @@ struct DevScene {
     uint32_t n_prims, n_tris, n_spheres, n_lights, n_materials;
     uint32_t uses_bvh;
     uint32_t has_transparent;   // some material has transparency != 0
-    uint32_t has_area_light;
+    uint32_t n_area_lights;     // lights of type RTX_LIGHT_AREA (each takes num_samples shadow rays per hit)
     // shading-side arrays, indexed through prim_ref by reference primitive id
     const uint32_t* prim_ref;   // [n_prims] bit 31 set = sphere; low 31 bits = index into its type's arrays
     const float* tri_pos;       // [n_tris][9]
@@ -118,7 +118,8 @@ struct rtx_context {
     // render workspace (grown on demand)
     std::vector<void*> work_allocs;
     uint64_t work_batch = 0;      // pixels per batch the workspace was sized for
-    uint32_t work_lights = 0;
+    uint32_t work_slots = 0;      // shadow-term slots per node the workspace was sized for
+    bool work_keys = false;       // the workspace holds per-node sampling keys (area lights)
 
     std::vector<char> work_blob;  // the Work struct of rtx_shade.hip describing work_allocs
     std::vector<hipEvent_t> events;

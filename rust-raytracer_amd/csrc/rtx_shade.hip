@@ -40,12 +40,24 @@ struct Work {
     RayQueue q[2];
     uint32_t cap_rays;
     float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir, pool slot) (cd, -)
-    float* shadow;               // [n_lights][cap_rays] shadow scalars
+    // Shadow terms, [n_slots][cap_rays]: one slot per sample of shadow_scalar's loop (lib.rs:113-135).
+    // Light j owns slots first_slot(j) .. + n_j - 1, n_j = n_samples for an area light, else 1,
+    // first_slot(j) = j + area_before(j) * (n_samples - 1).
+    float* shadow;
     float4 *pL, *pC0, *pC1;      // retained pool: (local colour, mat0), reflected child colour, refracted child colour
     uint32_t* pLink;             // retained pool: parent link
+    uint64_t* pKey;              // retained pool: sampling key of the node; nullptr without area lights
     uint32_t cap_pool;
+    uint32_t n_samples;          // RayTracer::num_samples, at least 1 here
+    uint32_t area_off;           // num_samples == 0: area lights trace nothing and contribute nothing
     Ctl* ctl;
 };
+
+// Where a level-0 link (ray index of the rank) lies in the image.
+struct PixMap {
+    uint32_t level0, rank, world, tiles_x, width;
+};
+RTX_D uint32_t first_slot(const DevLight& l, uint32_t j, uint32_t n_samples) { return j + l.area_before * (n_samples - 1u); }
 
 struct CamSetup {   // RayTracer fields after setup_camera (lib.rs:69-84) plus the two plane vectors (lib.rs:86-94)
     V3 center, cam_pos, hplane, vplane;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue 
 // slots with ONE atomic, so the node order follows the ray order inside a chunk and
 // the global counter sees ~n/2048 atomics instead of one per wavefront.
 constexpr int kShadeItems = 8;
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi) {
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm) {
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
     __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
@@ -261,100 +273,165 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             wk.nV[node] = make_float4(d.x, d.y, d.z, u2f(slot));
             wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);
             wk.pLink[slot] = f2u(o4.w);
+            if (wk.pKey) {   // the node's sampling key: hash of the pixel, extended along the path through the ray tree
+                const uint32_t link = f2u(o4.w);
+                uint64_t key;
+                if (pm.level0) {
+                    const uint32_t tile = (link >> 6) * pm.world + pm.rank, ln = link & 63u;
+                    const uint32_t x = (tile % pm.tiles_x) * RTX_TILE + (ln & 7u), y = (tile / pm.tiles_x) * RTX_TILE + (ln >> 3);
+                    key = rng_mix64((uint64_t)y * pm.width + x);
+                } else {
+                    key = rng_push(wk.pKey[link & 0x7fffffffu], (link >> 31) ? kKeyRefract : kKeyReflect);
+                }
+                wk.pKey[slot] = key;
+            }
         }
         if (panic) atomicAdd(&ctl->stat[ST_PANIC], 1ull);   // rare
         __syncthreads();
     }
 }
 
-// Forward step 2: RayTracer::shadow_scalar (lib.rs:105-141), one (node, light) task
-// per lane, tasks ordered light-major so a wavefront's rays converge on one light.
+// Forward step 2: RayTracer::shadow_scalar (lib.rs:105-141). One lane takes one sample of
+// the outermost call's loop for one (node, light): a task is (slot, node), ordered
+// slot-major so that a wavefront's rays converge on one light. The task stores the
+// sample's term; k_shade_b adds a light's terms in sample order and divides by n.
 // ANY: scenes without transparent materials, the first occluder ends the search.
-// Otherwise: closest hit, continued through transparent hits up to `depth` times; the
-// chain's transparencies are parked in the top of the lane's spill column so that the
-// products can be formed innermost-first exactly as the recursion does.
+// Otherwise: closest hit, and a transparent hit recurses (lib.rs:129) -- for an area light
+// that inner call loops over n samples of its own. The recursion runs in the lane with an
+// explicit stack of frames (origin, key, sample number, partial sum, kt: 8 words) parked
+// in the top of the lane's spill column, so sums and products are formed in the
+// reference's order. AREA: some light is an area light (keys are derived, see rng_push).
+constexpr int kFrameWords = 8;
+template <bool AREA>
 struct ShadowTask {
     const DevScene* s;
     Work wk;
-    uint32_t nn, depth;
+    uint32_t nn, depth, pool_base;
     TravStack* st;
-    uint32_t j, node;    // current task
-    uint32_t rem;        // remaining recursion depth of shadow_scalar
-    int chain;           // transparent hits passed so far
+    uint32_t slot, node, j;   // current task
+    uint32_t n;          // samples per shadow_scalar call for this light
+    uint32_t rem;        // remaining recursion depth of the call whose sample is being traced
+    int frames;          // suspended calls
+    uint64_t ks;         // key of the sample being traced
     unsigned long long rays;
 
-    RTX_D void store(float v) { wk.shadow[(size_t)j * wk.cap_rays + node] = v; }
-    RTX_D int* kt_slot(int k) { return st->spill + (size_t)(s->spill_entries - 1 - (uint32_t)k) * st->spill_stride; }
+    RTX_D void store(float v) { wk.shadow[(size_t)slot * wk.cap_rays + node] = v; }
+    RTX_D int* frame_word(int f, int w) {
+        return st->spill + (size_t)(s->spill_entries - 1 - (uint32_t)(f * kFrameWords + w)) * st->spill_stride;
+    }
     // Sets up the shadow ray of task `item`; false when the light is skipped (fattj <= 0, lib.rs:218).
     RTX_D bool start(uint32_t item, V3& o, V3& d, float& dl) {
-        j = item / nn;
-        node = item - j * nn;
+        slot = item / nn;
+        node = item - slot * nn;
+        j = slot;
+        uint32_t smp = 0;
+        if (AREA) {
+            j = 0;
+            for (uint32_t k = 0; k < s->n_lights; ++k) {
+                const uint32_t first = k + s->lights[k].area_before * (wk.n_samples - 1u);
+                if (first <= slot) {
+                    j = k;
+                    smp = slot - first;
+                }
+            }
+        }
         const DevLight light = s->lights[j];
+        n = (AREA && light.type == RTX_LIGHT_AREA) ? wk.n_samples : 1u;
+        if (AREA && light.type == RTX_LIGHT_AREA && wk.area_off) {
+            store(0.0f);
+            return false;
+        }
         const float4 p4 = wk.nP[node], n4 = wk.nN[node];
         const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z);
-        if (!(calculate_fattj(light, point) > 0.0f)) {
+        uint64_t kl = 0;
+        if (AREA) kl = rng_push(wk.pKey[pool_base + node], kKeyLight + j);
+        if (!(calculate_fattj(light, point, AREA ? rng_push(kl, 0) : 0ull) > 0.0f)) {
             store(0.0f);
             return false;
         }
         o = point + vmult(normal, 0.0001f);                   // lib.rs:111
-        d = light_dir(light, o);
-        dl = (light.type == RTX_LIGHT_DIRECTIONAL) ? -1.0f : vdistance(o, light_pos(light));
+        ks = AREA ? rng_push(rng_push(kl, 1), kKeyShadowSample + smp) : 0ull;
+        d = light_dir(light, o, AREA ? rng_push(ks, 1) : 0ull);
+        dl = (light.type == RTX_LIGHT_DIRECTIONAL) ? -1.0f : vdistance(o, light_pos(light, AREA ? rng_push(ks, 2) : 0ull));
         rem = depth;
-        chain = 0;
+        frames = 0;
         ++rays;
         return true;
     }
-    RTX_D void finish_any(bool occluded) { store(clamp01((0.0f + (occluded ? 0.0f : 1.0f)) / 1.0f)); }
+    RTX_D void finish_any(bool occluded) { store(occluded ? 0.0f : 1.0f); }
     // Closest-hit form: (id, t) is the closest hit of the ray (o, d). True: continue with the new ray in o/d.
     RTX_D bool finish_closest(int id, float t, V3& o, V3& d) {
         const DevLight light = s->lights[j];
-        float term = 1.0f;
+        float term = 1.0f;                                    // Missed, lib.rs:133
         if (id >= 0) {
             const HitGeom g = hit_geometry(*s, id, o, d, t, false);
             const rtx_material* m = material_or_null(*s, g.mat0);
             const float kt = m ? m->transparency : 0.0f;
-            if (kt == 0.0f) {
+            if (kt == 0.0f) {                                 // lib.rs:120-128
                 term = (light.type == RTX_LIGHT_DIRECTIONAL)
                            ? 0.0f
-                           : ((vdistance(o, g.p) > vdistance(o, light_pos(light))) ? 1.0f : 0.0f);
-            } else {
-                *kt_slot(chain) = (int)f2u(kt);       // kt * shadow_scalar(hit, depth - 1)
-                ++chain;
+                           : ((vdistance(o, g.p) > vdistance(o, light_pos(light, AREA ? rng_push(ks, 2) : 0ull))) ? 1.0f : 0.0f);
+            } else if (rem - 1u == 0u) {
+                term = kt * 0.0f;                             // depth exhausted: the inner call returns Color::new()
+            } else {                                          // kt * shadow_scalar(hit, n, depth - 1), lib.rs:129
+                const V3 ori = g.p + vmult(g.n, 0.0001f);
+                const uint64_t key = AREA ? rng_push(ks, 3) : 0ull;
+                *frame_word(frames, 0) = (int)f2u(ori.x);
+                *frame_word(frames, 1) = (int)f2u(ori.y);
+                *frame_word(frames, 2) = (int)f2u(ori.z);
+                *frame_word(frames, 3) = (int)(uint32_t)key;
+                *frame_word(frames, 4) = (int)(uint32_t)(key >> 32);
+                *frame_word(frames, 5) = 0;
+                *frame_word(frames, 6) = (int)f2u(0.0f);
+                *frame_word(frames, 7) = (int)f2u(kt);
+                ++frames;
                 --rem;
-                if (rem != 0) {
-                    o = g.p + vmult(g.n, 0.0001f);
-                    d = light_dir(light, o);
-                    ++rays;
-                    return true;
-                }
-                term = -1.0f;                         // depth exhausted: the innermost call returns Color::new()
+                ks = AREA ? rng_push(key, kKeyShadowSample) : 0ull;
+                o = ori;
+                d = light_dir(light, o, AREA ? rng_push(ks, 1) : 0ull);
+                ++rays;
+                return true;
             }
         }
-        float inner = (term < 0.0f) ? 0.0f : clamp01((0.0f + term) / 1.0f);
-        while (chain > 0) {                           // products innermost-first, as the recursion forms them
-            --chain;
-            inner = clamp01((0.0f + u2f((uint32_t)*kt_slot(chain)) * inner) / 1.0f);
+        while (frames > 0) {                                  // the sample's term goes to the innermost suspended call
+            const int f = frames - 1;
+            const float shade = u2f((uint32_t)*frame_word(f, 6)) + term;
+            const uint32_t smp = (uint32_t)*frame_word(f, 5) + 1u;
+            if (smp < n) {                                    // next sample of that call
+                *frame_word(f, 5) = (int)smp;
+                *frame_word(f, 6) = (int)f2u(shade);
+                const uint64_t key = (uint64_t)(uint32_t)*frame_word(f, 3) | ((uint64_t)(uint32_t)*frame_word(f, 4) << 32);
+                ks = AREA ? rng_push(key, kKeyShadowSample + smp) : 0ull;
+                o = v3(u2f((uint32_t)*frame_word(f, 0)), u2f((uint32_t)*frame_word(f, 1)), u2f((uint32_t)*frame_word(f, 2)));
+                d = light_dir(light, o, AREA ? rng_push(ks, 1) : 0ull);
+                ++rays;
+                return true;
+            }
+            term = u2f((uint32_t)*frame_word(f, 7)) * clamp01(shade / (float)n);   // kt * Color::init(shade / n).r
+            --frames;
+            ++rem;
         }
-        store(inner);
+        store(term);
         return false;
     }
 };
 
-template <bool ANY>
-__global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint32_t depth) {
+template <bool ANY, bool AREA>
+__global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     TravStack st;
     st.set(lds, s);
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
-    ShadowTask task;
+    ShadowTask<AREA> task;
     task.s = &s;
     task.wk = wk;
     task.nn = min(ctl->n_nodes, wk.cap_rays);
+    task.pool_base = ctl->pool_base;
     task.depth = depth;
     task.st = &st;
     task.rays = 0;
-    const uint64_t total = min((uint64_t)task.nn * s.n_lights, (uint64_t)0xfffffff0u);
+    const uint64_t total = min((uint64_t)task.nn * n_slots, (uint64_t)0xfffffff0u);
     UnitQueue uq;
     uq.init(&ctl->unit_head[1][0][0], total);
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
@@ -413,7 +490,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_p(DevScene s, RayQueue q, C
 
 template <bool ANY>
 struct ShadowJob {
-    ShadowTask task;
+    ShadowTask<false> task;
     RTX_D bool start(uint32_t item, V3& o, V3& d, float& dl) { return task.start(item, o, d, dl); }
     RTX_D bool finish(const Trav& tr, V3& o, V3& d, float& dl) {
         if (ANY) {
@@ -438,6 +515,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uin
     job.task.s = &s;
     job.task.wk = wk;
     job.task.nn = min(ctl->n_nodes, wk.cap_rays);
+    job.task.pool_base = ctl->pool_base;
     job.task.depth = depth;
     job.task.st = &st;
     job.task.rays = 0;
@@ -449,7 +527,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uin
 }
 
 // Forward step 3: local colour and children.
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth) {
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples) {
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     const uint32_t nn = ctl->n_nodes;
@@ -474,13 +552,20 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
             const Col ka = m ? col_raw(m->ambient) : col_new();
             const Col ambient_light = col_mult(cd * ka, 1.0f - kt);   // lib.rs:143-145
             Col direct_light = col_new();
+            const uint64_t key = wk.pKey ? wk.pKey[slot] : 0ull;
             for (uint32_t j = 0; j < s.n_lights; ++j) {              // lib.rs:216-228, scene order
                 const DevLight light = s.lights[j];
-                const float fattj = calculate_fattj(light, point);
+                const bool area = light.type == RTX_LIGHT_AREA;
+                const uint64_t kl = area ? rng_push(key, kKeyLight + j) : 0ull;
+                const float fattj = calculate_fattj(light, point, area ? rng_push(kl, 0) : 0ull);
                 if (fattj > 0.0f) {
-                    const float ss = wk.shadow[(size_t)j * wk.cap_rays + node];
+                    const uint32_t n = area ? n_samples : 1u;         // lib.rs:219-222
+                    const float* term = wk.shadow + (size_t)first_slot(light, j, wk.n_samples) * wk.cap_rays + node;
+                    float shade = 0.0f;                               // lib.rs:112-138
+                    for (uint32_t smp = 0; smp < n; ++smp) shade += term[(size_t)smp * wk.cap_rays];
+                    shade = clamp01(shade / (float)n);
                     direct_light = direct_light + direct_lightning(light, point, normal, dir, cd, ks, kt, shininess,
-                                                                   Col{ss, ss, ss}, fattj);
+                                                                   Col{shade, shade, shade}, fattj, n, area ? rng_push(kl, 2) : 0ull);
                 }
             }
             const Col local = direct_light + ambient_light;           // first '+' of lib.rs:254
@@ -609,10 +694,11 @@ int walloc(rtx_context* ctx, T** out, size_t count) {
     return RTX_OK;
 }
 
-int ensure_workspace(rtx_context* ctx, uint64_t batch, Work* out) {
+int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out) {
     static_assert(sizeof(Work) < 512, "Work is passed by value");
-    const uint32_t lights = std::max<uint32_t>(ctx->ds.n_lights, 1);
-    if (ctx->work_batch >= batch && ctx->work_lights >= lights && ctx->work_blob.size() == sizeof(Work)) {
+    slots = std::max<uint32_t>(slots, 1);
+    const bool keys = ctx->ds.n_area_lights != 0;
+    if (ctx->work_batch >= batch && ctx->work_slots >= slots && ctx->work_keys == keys && ctx->work_blob.size() == sizeof(Work)) {
         std::memcpy(out, ctx->work_blob.data(), sizeof(Work));
         return RTX_OK;
     }
@@ -634,15 +720,17 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, Work* out) {
     W_TRY(walloc(ctx, &wk.nN, wk.cap_rays));
     W_TRY(walloc(ctx, &wk.nV, wk.cap_rays));
     W_TRY(walloc(ctx, &wk.nC, wk.cap_rays));
-    W_TRY(walloc(ctx, &wk.shadow, (size_t)wk.cap_rays * lights));
+    W_TRY(walloc(ctx, &wk.shadow, (size_t)wk.cap_rays * slots));
     W_TRY(walloc(ctx, &wk.pL, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.pC0, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.pC1, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.pLink, wk.cap_pool));
+    if (keys) W_TRY(walloc(ctx, &wk.pKey, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.ctl, 1));
 #undef W_TRY
     ctx->work_batch = batch;
-    ctx->work_lights = lights;
+    ctx->work_slots = slots;
+    ctx->work_keys = keys;
     ctx->work_blob.assign((const char*)&wk, (const char*)&wk + sizeof(Work));
     *out = wk;
     return RTX_OK;
@@ -689,12 +777,16 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
         hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);
     }
 }
-void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, bool any, hipStream_t st) {
+void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
+                   hipStream_t st) {
     const DevScene& s = ctx->ds;
-    if (ctx->opt_trace_variant == 0) {
-        const dim3 grid(trav_blocks(ctx, tasks_upper));
-        if (any) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
-        else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(RTX_BLOCK), 0, st, s, wk, depth);
+    const bool area = s.n_area_lights != 0;
+    if (ctx->opt_trace_variant == 0 || area) {   // the persistent variant has no sample slots
+        const dim3 grid(trav_blocks(ctx, tasks_upper)), block(RTX_BLOCK);
+        if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots);
+        else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots);
+        else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots);
+        else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots);
     } else {
         const PersistGrid g = persist_grid(ctx, tasks_upper);
         if (any) hipLaunchKernelGGL(k_shadow_p<true>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
@@ -712,11 +804,14 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
                     uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct) {
-    (void)samples;   // num_samples only multiplies area-light rays (lib.rs:219-222)
     const DevScene& s = ctx->ds;
     hipStream_t st = ctx->stream;
     if (depth > RTX_MAX_DEPTH) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "depth above RTX_MAX_DEPTH");
-    if (s.has_area_light) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "area lights are not implemented on the device yet");
+    // num_samples only multiplies area-light rays (lib.rs:219-222)
+    const uint32_t n_samples = s.n_area_lights ? std::max<uint32_t>(samples, 1) : 1;
+    const uint64_t n_slots64 = (uint64_t)s.n_lights + (uint64_t)s.n_area_lights * (n_samples - 1);
+    if (n_slots64 > 4096) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "more than 4096 shadow samples per hit");
+    const uint32_t n_slots = (uint32_t)n_slots64;
     const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE, tiles_y = (h + RTX_TILE - 1) / RTX_TILE;
     const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
     if (n_tiles >= (1ull << 25)) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "image too large");
@@ -747,9 +842,14 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
 
     uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays_local, 64));
     batch = (batch + 63) & ~63ull;
+    // shadow tasks of one level (rays x slots) are indexed with 32 bits; this also keeps the
+    // shadow-term array of a many-sample frame near 1 GiB
+    batch = std::max<uint64_t>(64, std::min<uint64_t>(batch, ((1ull << 27) / std::max<uint32_t>(n_slots, 1)) & ~63ull));
     Work wk;
-    int rc = ensure_workspace(ctx, batch, &wk);
+    int rc = ensure_workspace(ctx, batch, n_slots, &wk);
     if (rc != RTX_OK) return rc;
+    wk.n_samples = n_samples;
+    wk.area_off = (s.n_area_lights && samples == 0) ? 1u : 0u;
     RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
 
     const CamSetup cam = make_cam(ctx->camera, w, h);
@@ -782,17 +882,18 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             launch_closest(ctx, wk, qi, n_rays, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi);
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
+                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w});
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
                 RTX_HIP(ctx, hipEventRecord(c, st));
-                const uint64_t tasks = (uint64_t)n_rays * s.n_lights;
-                launch_shadow(ctx, wk, depth - level, tasks, any_shadow, st);
+                const uint64_t tasks = (uint64_t)n_rays * n_slots;
+                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, st);
                 RTX_HIP(ctx, hipEventRecord(d, st));
                 shadow_events.emplace_back(c, d);
             }
-            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level);
+            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples);
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
             levels_done = level + 1;
             if (level + 1 < levels) {
@@ -872,7 +973,7 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
     uint64_t batch = std::min<uint64_t>(std::max<int64_t>(ctx->opt_batch_pixels, 64), std::max<uint64_t>(rays, 64));
     batch = (batch + 63) & ~63ull;
     Work wk;
-    int rc = ensure_workspace(ctx, batch, &wk);
+    int rc = ensure_workspace(ctx, batch, ctx->ds.n_lights, &wk);
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
     const CamSetup cam = make_cam(ctx->camera, w, h);

@@ -104,40 +104,77 @@ RTX_D bool refractive_ray(V3 in_dir, V3 point, V3 normal, bool in_vacuum, V3& ro
     return true;
 }
 
-// Light::position / Light::get_dir for point and directional lights (scene/mod.rs:35-59).
-RTX_D V3 light_pos(const DevLight& l) {
+// Area lights. The reference draws AreaLight::sample_point from an OS-seeded generator
+// (scene/mod.rs:94-96), so its images are not reproducible; here every draw is a pure
+// function of a 64-bit key that names the draw: (pixel, path through the ray tree, light,
+// call site, sample number). Keys are derived with rng_push along that path.
+RTX_D uint64_t rng_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RTX_D uint64_t rng_push(uint64_t key, uint64_t v) { return rng_mix64(key ^ rng_mix64(v)); }
+RTX_D float rng_open01(uint64_t h) {   // 23 random bits -> a float strictly inside (0, 1)
+    return ((float)(uint32_t)(h >> 41) + 0.5f) * (1.0f / 8388608.0f);
+}
+// Key offsets of the draws (one namespace per call site of the reference).
+constexpr uint64_t kKeyLight = 0x1000;     // + light index, shade_intersection's loop (lib.rs:216)
+constexpr uint64_t kKeyShadowSample = 0x100;   // + sample, shadow_scalar's loop (lib.rs:113)
+constexpr uint64_t kKeyDirectSample = 0x200;   // + sample, direct_lightning's loop (lib.rs:181)
+constexpr uint64_t kKeyReflect = 0x2000, kKeyRefract = 0x3000;   // children of a node (lib.rs:234,244)
+
+// AreaLight::sample_point (scene/mod.rs:93-104): a = min corner, b = max corner.
+RTX_D V3 area_sample_point(const DevLight& l, uint64_t key) {
+    const float rx = rng_open01(rng_mix64(key ^ 1)), ry = rng_open01(rng_mix64(key ^ 2)), rz = rng_open01(rng_mix64(key ^ 3));
+    float dx = fabsf(l.b[0] - l.a[0]) * 0.5f;
+    float dy = fabsf(l.b[1] - l.a[1]) * 0.5f;
+    float dz = fabsf(l.b[2] - l.a[2]) * 0.5f;
+    dx = dx - rx * (dx * 2.0f);
+    dy = dy - ry * (dy * 2.0f);
+    dz = dz - rz * (dz * 2.0f);
+    return v3(l.b[0] + dx, l.b[1] + dy, l.b[2] + dz);
+}
+// Light::position / Light::get_dir (scene/mod.rs:35-59); `key` is only read for area lights.
+RTX_D V3 light_pos(const DevLight& l, uint64_t key) {
+    if (l.type == RTX_LIGHT_AREA) return area_sample_point(l, key);
     return (l.type == RTX_LIGHT_POINT) ? v3(l.a[0], l.a[1], l.a[2]) : v3(0.0f, 0.0f, 0.0f);
 }
-RTX_D V3 light_dir(const DevLight& l, V3 point) {
+RTX_D V3 light_dir(const DevLight& l, V3 point, uint64_t key) {
     if (l.type == RTX_LIGHT_DIRECTIONAL) return vinvert(v3(l.a[0], l.a[1], l.a[2]));
+    if (l.type == RTX_LIGHT_AREA) return vnormalize(area_sample_point(l, key) - point);
     return vnormalize(v3(l.a[0], l.a[1], l.a[2]) - point);
 }
 // RayTracer::calculate_fattj (lib.rs:147-155)
-RTX_D float calculate_fattj(const DevLight& l, V3 point) {
+RTX_D float calculate_fattj(const DevLight& l, V3 point, uint64_t key) {
     if (l.type == RTX_LIGHT_DIRECTIONAL) return 1.0f;
-    const float dist = vdistance(point, light_pos(l));
+    const float dist = vdistance(point, light_pos(l, key));
     return fminf(1.0f, 1.0f / (0.25f + 0.1f * dist + 0.01f * dist * dist));
 }
-// RayTracer::direct_lightning for one sample (lib.rs:171-199 with n == 1)
+// RayTracer::direct_lightning (lib.rs:171-199): n = num_samples for an area light, else 1;
+// `key` names this call, sample s draws with key + kKeyDirectSample + s.
 RTX_D Col direct_lightning(const DevLight& l, V3 point, V3 normal, V3 ray_dir, Col cd, Col ks, float kt,
-                           float shininess, Col sj, float fattj) {
+                           float shininess, Col sj, float fattj, uint32_t n, uint64_t key) {
     const float q = shininess * 128.0f;
     const Col direct_light = col_mult(col_raw(l.color) * sj, fattj);
     Col lightning = col_new();
-    const V3 dir = light_dir(l, point);
-    // diffuse_lightning (lib.rs:157-161)
-    const float a = 1.0f - kt;
-    const float b = fmaxf(0.0f, vdot(normal, dir));
-    const Col diffuse_light = col_mult(cd, a * b);
-    // specular_lightning (lib.rs:163-169)
-    const V3 v = vinvert(ray_dir);
-    float t = vdot(normal, dir);
-    V3 rj = vmult(vmult(normal, t), 2.0f);
-    rj = rj - dir;
-    t = fmaxf(vdot(rj, v), 0.0f);
-    const Col specular_light = col_mult(ks, powf(t, q));
-    Col sample = direct_light * (diffuse_light + specular_light);
-    sample = col_init(sample.r / 1.0f, sample.g / 1.0f, sample.b / 1.0f);
-    lightning = lightning + sample;
+    const float nf = (float)n;
+    for (uint32_t smp = 0; smp < n; ++smp) {
+        const V3 dir = light_dir(l, point, (l.type == RTX_LIGHT_AREA) ? rng_push(key, kKeyDirectSample + smp) : 0ull);
+        // diffuse_lightning (lib.rs:157-161)
+        const float a = 1.0f - kt;
+        const float b = fmaxf(0.0f, vdot(normal, dir));
+        const Col diffuse_light = col_mult(cd, a * b);
+        // specular_lightning (lib.rs:163-169)
+        const V3 v = vinvert(ray_dir);
+        float t = vdot(normal, dir);
+        V3 rj = vmult(vmult(normal, t), 2.0f);
+        rj = rj - dir;
+        t = fmaxf(vdot(rj, v), 0.0f);
+        const Col specular_light = col_mult(ks, powf(t, q));
+        Col sample = direct_light * (diffuse_light + specular_light);
+        sample = col_init(sample.r / nf, sample.g / nf, sample.b / nf);
+        lightning = lightning + sample;
+    }
     return lightning;
 }

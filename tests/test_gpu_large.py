@@ -108,6 +108,19 @@ def test_frame_is_reproducible_and_shardable(big, rtx):
     assert np.array_equal(img.cpu().numpy().reshape(h, w, 3), a)
 
 
+def test_render_device_writes_the_same_row_major_frame(big):
+    """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
+    import torch
+    _, ctx = big
+    for w, h in ((1920, 1080), (333, 77)):
+        a, sa = ctx.render(w, h, 10, 10)
+        img = torch.full((h * w * 3,), 7, dtype=torch.uint8, device="cuda:0")
+        sb = ctx.render_device(w, h, 10, 10, img.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(img.cpu().numpy().reshape(h, w, 3), a)
+        assert sa.traced_rays == sb.traced_rays and sb.closest_launches == 1 and sb.shadow_launches == 1
+
+
 def test_small_batches_give_the_same_frame(rtx, synth):
     flat = synth.heightfield_scene(64, spec=0.3, glass_lattice=3)
     with rtx.Context(0) as ctx:
