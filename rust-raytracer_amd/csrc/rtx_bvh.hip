@@ -334,13 +334,23 @@ __global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict_
 
 struct PadParams {
     float rel;        // boxes grow by rel * (largest |coordinate| of the box)
-    float sphere_k;   // sphere boxes additionally grow to sqrt(r^2 + sphere_k) - r
 };
+
+// Positive finite f32 -> f16 bits, rounded toward zero (NaN and values <= 0 give 0).
+__device__ __forceinline__ uint32_t f16_bits_down(float r) {
+    if (!(r > 0.0f)) return 0u;
+    if (r >= 65504.0f) return 0x7bffu;
+    const uint32_t b = __float_as_uint(r);
+    const int e = (int)(b >> 23) - 127;
+    if (e >= -14) return ((uint32_t)(e + 15) << 10) | ((b & 0x7fffffu) >> 13);
+    return (uint32_t)(r * 16777216.0f);   // subnormal f16: multiples of 2^-24, truncated
+}
 
 // Leaves: padded primitive boxes. Padding covers primitive tests that accept a
 // ray passing marginally outside the exact shape (f32 rounding in
-// Moeller-Trumbore; cancellation in the sphere discriminant, which is
-// proportional to the squared distance between ray origin and centre).
+// Moeller-Trumbore). The sphere discriminant's cancellation error grows with the
+// distance between ray origin and centre; it is covered at traversal time from
+// the smallest sphere radius of each subtree, carried in nmin[].w (+inf: no sphere).
 __global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
                                                          const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                                                          float4* __restrict__ nmin, float4* __restrict__ nmax,
@@ -354,12 +364,13 @@ __global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, 
     float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
     float pad = pp.rel * m + 1e-30f;
     const uint32_t ref = s.prim_ref[id];
+    float rmin = __builtin_inff();
     if (ref >> 31) {
-        const float r = fabsf(s.sph[ref & 0x7fffffffu].w);
-        pad += sqrtf(r * r + pp.sphere_k) - r;
+        rmin = fabsf(s.sph[ref & 0x7fffffffu].w);
+        if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
     }
     const uint32_t node = (n - 1) + j;
-    nmin[node] = make_float4(a.x - pad, a.y - pad, a.z - pad, 0.0f);
+    nmin[node] = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
     nmax[node] = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
     theight[node] = 0;
     if (n > 1) {
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
         const int i = qin[k];
         const int l = child_l[i], r = child_r[i];
         const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
-        nmin[i] = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), 0.0f);  // BoundingBox + , shapes/mod.rs:86-104
+        nmin[i] = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), fminf(la.w, ra.w));  // BoundingBox + , shapes/mod.rs:86-104
         nmax[i] = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
         const int size = rng_last[i] - rng_first[i] + 1;
         const int h = (size <= leaf_max) ? 0 : 1 + max((int)theight[l], (int)theight[r]);
@@ -460,8 +471,14 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
         const float ext[3] = {bmx.x - bmn.x, bmx.y - bmn.y, bmx.z - bmn.z};
         uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, eb[3];
         float cmn[4][3], cmx[4][3];
+        uint32_t rcode[4] = {0x7c00u, 0x7c00u, 0x7c00u, 0x7c00u};   // smallest sphere radius per child, f16; +inf = none
+        bool spheres = false;
         for (int k = 0; k < nc; ++k) {
             const float4 a = nmin[ch[k]], b = nmax[ch[k]];
+            if (a.w < __builtin_inff()) {
+                rcode[k] = f16_bits_down(a.w);
+                spheres = true;
+            }
             cmn[k][0] = a.x; cmn[k][1] = a.y; cmn[k][2] = a.z;
             cmx[k][0] = b.x; cmx[k][1] = b.y; cmx[k][2] = b.z;
         }
@@ -496,10 +513,10 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
         for (int k = 0; k < nc; ++k) ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves, leaf_max);
         BvhNode nd;
         nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
-                          eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24));
+                          eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (spheres ? 0x80000000u : 0u));
         nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
         nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
-        nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], 0u, 0u);
+        nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], rcode[0] | (rcode[1] << 16), rcode[2] | (rcode[3] << 16));
         nodes[i] = nd;
         my_nodes = 1;
     }
@@ -612,8 +629,6 @@ int rtx_bvh_build(rtx_context* ctx) {
     s.pad_rel = 1.0f / 131072.0f;   // 2^-17, about 128 ulp of the coordinate magnitude
     PadParams pp;
     pp.rel = s.pad_rel;
-    const float dmax = 1.7320508f * (s.safe_r + radius);   // farthest origin-to-centre distance inside the safe cube
-    pp.sphere_k = (1.0f / 524288.0f) * dmax * dmax;        // 2^-19 * D^2, ~32 roundings of |o - c|^2
 
     const int leaf_max = std::min<int>(std::max<int>(ctx->opt_tune[3], 1), 8);
     const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > (uint32_t)leaf_max)

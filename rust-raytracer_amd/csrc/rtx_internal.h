@@ -24,12 +24,15 @@
 //
 // BvhNode (64 B, four quads): a 4-wide node with quantised child boxes; one traversal
 // step covers two levels of the binary tree for one 64-byte fetch.
-//   a = (bits(origin.x), bits(origin.y), bits(origin.z), ex | ey<<8 | ez<<16 | n_children<<24)
+//   a = (bits(origin.x), bits(origin.y), bits(origin.z), ex | ey<<8 | ez<<16 | n_children<<24 | spheres<<31)
 //       origin = lower corner of the node's box; e* = biased f32 exponent of the per-axis
-//       grid step (step = 2^(e-127)); n_children = 2..4, children are packed first
+//       grid step (step = 2^(e-127)); n_children = 2..4, children are packed first;
+//       spheres = 1 when some child's subtree holds a sphere
 //   b = (qlo_x[4], qlo_y[4], qlo_z[4], qhi_x[4])   one byte per child: plane = origin + q * step
 //   c = (qhi_y[4], qhi_z[4], ref[0], ref[1])
-//   d = (ref[2], ref[3], 0, 0)
+//   d = (ref[2], ref[3], rmin[0] | rmin[1]<<16, rmin[2] | rmin[3]<<16)
+//       rmin = smallest sphere radius below the child as f16 rounded down (0x7c00 = no sphere):
+//       sphere children are widened per ray at traversal time (kSphereK, rtx_traverse.h)
 // qlo is rounded down and qhi up, so a child's quantised box contains its padded box.
 // ref >= 0: index of another BvhNode; ref < 0: ~ref = (first << 3) | (count - 1),
 // a leaf of `count` (1..8) consecutive PrimRecs starting at `first`.

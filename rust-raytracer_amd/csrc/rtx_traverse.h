@@ -113,6 +113,45 @@ struct TravStack {
     }
 };
 
+// Sphere tests accept rays that miss: the discriminant b*b - 4ac (sphere.rs:62-67) is a
+// difference of two numbers near 4|d|^2 D^2 (D = distance from the ray origin to the
+// centre), each carrying a few roundings, so a ray passing within sqrt(r^2 + K D^2) of the
+// centre can still report a hit (worst case of the f32 operations: K = 16 * 2^-24; the
+// constant below adds a margin). The excess over r depends on the ray, so it is not baked
+// into the boxes: a node whose subtree holds spheres is flagged and stores, per child, the
+// smallest sphere radius below it (f16, rounded down); the traversal widens such a child by
+//     e = K Dn^2 / (sqrt(rmin^2 + K Dn^2) + rmin),   Dn = distance to the node's farthest corner,
+// which bounds sqrt(r^2 + K D^2) - r for every sphere in the child (decreasing in r,
+// increasing in D). Children without spheres store +inf and get e = 0.
+#ifndef RTX_SPHERE_K
+#define RTX_SPHERE_K 1.25e-6f   // 21 * 2^-24
+#endif
+constexpr float kSphereK = RTX_SPHERE_K;
+
+template <bool WIDEN>
+RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const RayBox& rb, float limit, float sx, float sy,
+                       float sz, float lx, float ly, float lz, float hx, float hy, float hz, const float* e, float* t) {
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 8 * k;
+        const float ax = __builtin_fmaf((float)((B.x >> sh) & 0xffu), sx, lx), bx = __builtin_fmaf((float)((B.w >> sh) & 0xffu), sx, hx);
+        const float ay = __builtin_fmaf((float)((B.y >> sh) & 0xffu), sy, ly), by = __builtin_fmaf((float)((C.x >> sh) & 0xffu), sy, hy);
+        const float az = __builtin_fmaf((float)((B.z >> sh) & 0xffu), sz, lz), bz = __builtin_fmaf((float)((C.y >> sh) & 0xffu), sz, hz);
+        float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
+        float fx = fmaxf(ax, bx), fy = fmaxf(ay, by), fz = fmaxf(az, bz);
+        if (WIDEN) {   // planes move outward by e: e * |1/d| in ray parameter
+            const float wx = e[k] * fabsf(rb.inv.x), wy = e[k] * fabsf(rb.inv.y), wz = e[k] * fabsf(rb.inv.z);
+            nx -= wx; ny -= wy; nz -= wz;
+            fx += wx; fy += wy; fz += wz;
+        }
+        const float lo = fmaxf(fmaxf(nx, ny), nz);
+        const float hi = fminf(fminf(fx, fy), fz);
+        const bool hit = ((uint32_t)k < nchild) && (lo <= hi) && (hi >= 0.0f) && (lo <= limit);
+        t[k] = hit ? lo : inf;
+    }
+}
+
 // One step through a 4-wide node (layout: rtx_internal.h). The child boxes are
 // 8-bit offsets from the node's origin in units of a per-axis power of two, so the
 // slab test runs directly on the quantised values:
@@ -121,14 +160,13 @@ struct TravStack {
 // stays conservative. Children that are hit are ordered near to far; the nearest
 // becomes the next node and the others are pushed, farthest first.
 // Returns the next reference, or `done` when nothing is hit and the stack is empty.
-RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& rb, float limit, TravStack& st, int& sp,
+RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& rb, V3 o, float limit, TravStack& st, int& sp,
                      int done) {
     const uint4 A = nodes[cur].a, B = nodes[cur].b, C = nodes[cur].c, D = nodes[cur].d;
     const uint32_t meta = A.w;
-    const float sx = u2f((meta & 0xffu) << 23) * rb.inv.x;
-    const float sy = u2f(((meta >> 8) & 0xffu) << 23) * rb.inv.y;
-    const float sz = u2f(((meta >> 16) & 0xffu) << 23) * rb.inv.z;
-    const uint32_t nchild = meta >> 24;
+    const float stx = u2f((meta & 0xffu) << 23), sty = u2f(((meta >> 8) & 0xffu) << 23), stz = u2f(((meta >> 16) & 0xffu) << 23);
+    const float sx = stx * rb.inv.x, sy = sty * rb.inv.y, sz = stz * rb.inv.z;
+    const uint32_t nchild = (meta >> 24) & 7u;
     const float ox = u2f(A.x), oy = u2f(A.y), oz = u2f(A.z);
     const float lx = __builtin_fmaf(ox, rb.inv.x, -rb.oim.x), hx = __builtin_fmaf(ox, rb.inv.x, -rb.oip.x);
     const float ly = __builtin_fmaf(oy, rb.inv.y, -rb.oim.y), hy = __builtin_fmaf(oy, rb.inv.y, -rb.oip.y);
@@ -136,16 +174,25 @@ RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& r
     const float inf = __builtin_inff();
     float t[4];
     int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
+    if (meta >> 31) {   // spheres below: widen their children (see kSphereK)
+        const float dx = fmaxf(fabsf(ox - o.x), fabsf(__builtin_fmaf(255.0f, stx, ox) - o.x));
+        const float dy = fmaxf(fabsf(oy - o.y), fabsf(__builtin_fmaf(255.0f, sty, oy) - o.y));
+        const float dz = fmaxf(fabsf(oz - o.z), fabsf(__builtin_fmaf(255.0f, stz, oz) - o.z));
+        const float kd2 = kSphereK * (dx * dx + dy * dy + dz * dz);
+        float e[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int sh = 8 * k;
-        const float ax = __builtin_fmaf((float)((B.x >> sh) & 0xffu), sx, lx), bx = __builtin_fmaf((float)((B.w >> sh) & 0xffu), sx, hx);
-        const float ay = __builtin_fmaf((float)((B.y >> sh) & 0xffu), sy, ly), by = __builtin_fmaf((float)((C.x >> sh) & 0xffu), sy, hy);
-        const float az = __builtin_fmaf((float)((B.z >> sh) & 0xffu), sz, lz), bz = __builtin_fmaf((float)((C.y >> sh) & 0xffu), sz, hz);
-        const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-        const bool hit = ((uint32_t)k < nchild) && (lo <= hi) && (hi >= 0.0f) && (lo <= limit);
-        t[k] = hit ? lo : inf;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t hbits = (((k < 2) ? D.z : D.w) >> (16 * (k & 1))) & 0xffffu;
+            const unsigned short hs = (unsigned short)hbits;
+            _Float16 hf;
+            __builtin_memcpy(&hf, &hs, 2);
+            const float rq = (float)hf;
+            const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
+            e[k] = (hbits == 0x7c00u) ? 0.0f : kd2 * __builtin_amdgcn_rcpf(den) * 1.002f;
+        }
+        node4_slabs<true>(B, C, nchild, rb, limit, sx, sy, sz, lx, ly, lz, hx, hy, hz, e, t);
+    } else {
+        node4_slabs<false>(B, C, nchild, rb, limit, sx, sy, sz, lx, ly, lz, hx, hy, hz, nullptr, t);
     }
 #define RTX_CE(i, j)                                   \
     do {                                               \
@@ -178,7 +225,7 @@ RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float
     int cur = 0, sp = 0;
     while (cur != kRefDone) {
         if (cur >= 0) {
-            cur = node4_step(s.nodes, cur, rb, best_t, st, sp, kRefDone);
+            cur = node4_step(s.nodes, cur, rb, o, best_t, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
@@ -233,7 +280,7 @@ RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack&
     int cur = 0, sp = 0;
     while (cur != kRefDone) {
         if (cur >= 0) {
-            cur = node4_step(s.nodes, cur, rb, t_limit, st, sp, kRefDone);
+            cur = node4_step(s.nodes, cur, rb, o, t_limit, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;

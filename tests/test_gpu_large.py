@@ -160,6 +160,47 @@ def test_synthetic_scene_frame_equals_oracle(kind, rtx, synth, orc):
         (rs["shadow_rays"], rs["reflect_rays"], rs["refract_rays"], rs["last_level_rays"], rs["shaded_nodes"])
 
 
+def test_sphere_silhouette_rays_equal_exhaustive(rtx, synth):
+    """Rays aimed just inside and just outside sphere silhouettes from near and far origins:
+    the f32 discriminant (sphere.rs:62-67) accepts some rays that miss geometrically, and
+    the BVH must not cull those spheres. Ids and t bit for bit against the exhaustive kernel."""
+    flat = synth.heightfield_scene(32, small_spheres=60000)
+    big_r = flat.sph_center_radius.copy()
+    big_r[::7, 3] *= 40.0          # mixed radii: 5e-4 .. 3e-2
+    flat.sph_center_radius = big_r
+    rng = np.random.default_rng(23)
+    n = 60000
+    sph = flat.sph_center_radius[rng.integers(0, flat.n_spheres, n)].astype(np.float64)
+    c, r = sph[:, :3], sph[:, 3]
+    far = rng.random(n) < 0.5
+    ori = np.where(far[:, None], rng.normal(size=(n, 3)) * 3.0 + np.array([0.0, 4.0, 0.0]),
+                   c + rng.normal(size=(n, 3)) * (r[:, None] * rng.uniform(2.0, 50.0, n)[:, None]))
+    to_c = c - ori
+    dist = np.linalg.norm(to_c, axis=1)
+    u = to_c / dist[:, None]
+    perp = np.cross(u, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    # tangent direction: offset the target from the centre by r * (1 + eps), perpendicular to the view line
+    eps = rng.choice([-1e-3, -1e-5, -1e-6, -1e-7, 0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3], n)
+    foot = np.sqrt(np.maximum(dist ** 2 - r ** 2, 0.0))       # distance to the tangent point
+    target = ori + u * (foot ** 2 / dist)[:, None] + perp * ((r * foot / dist) * (1.0 + eps))[:, None]
+    d = target - ori
+    d[np.linalg.norm(d, axis=1) == 0.0] = (0.0, 1.0, 0.0)     # origin inside the sphere
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    d[::3] *= rng.uniform(0.2, 5.0, (len(d[::3]), 1))         # the tests take non-unit directions too
+    ori32, d32 = ori.astype(np.float32), d.astype(np.float32)
+    with rtx.Context(0) as ctx:
+        ctx.set_scene(flat)
+        ctx.build()
+        assert ctx.build_stats["uses_bvh"] == 1
+        pb, tb = ctx.intersect_batch(ori32, d32)
+        px, tx = ctx.intersect_batch(ori32, d32, exhaustive=True)
+    hit = px >= 0
+    assert 0.2 < hit.mean() < 1.0
+    assert np.array_equal(pb, px), "%d of %d rays differ" % ((pb != px).sum(), n)
+    assert np.array_equal(_bits(tb)[hit], _bits(tx)[hit])
+
+
 def test_errors_before_scene_and_build(rtx):
     with rtx.Context(0) as ctx:
         with pytest.raises(rtx.RtxError) as e:
