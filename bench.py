@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="traversal kernel variant (rtx_set_option trace_variant)")
     ap.add_argument("--tune", type=str, default="", help="comma-separated tune0..3 overrides (experiments)")
+    ap.add_argument("--backend", type=str, default="nccl",
+                    help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
+                         "collectives through host memory, ranks may share a GPU)")
     args = ap.parse_args()
 
     import torch
@@ -65,13 +68,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gloo = world > 1 and args.backend == "gloo"
+    dev_index = local_rank % torch.cuda.device_count() if gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if gloo else dev       # where collective buffers live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rtx = importlib.import_module("rust-raytracer_amd")
     synth = importlib.import_module("rust-raytracer_amd.synth")
@@ -80,10 +89,10 @@ def main():
     flat = synth.heightfield_scene(args.grid, spec=args.spec, glass_lattice=args.glass) if rank == 0 else None
     t_b0 = time.time()
     if world > 1:
-        flat = rdist.broadcast_scene(flat, 0, dev)
+        flat = rdist.broadcast_scene(flat, 0, cdev)
     bcast_ms = (time.time() - t_b0) * 1e3
 
-    ctx = rtx.Context(local_rank)
+    ctx = rtx.Context(dev_index)
     if args.variant:
         ctx.set_option("trace_variant", args.variant)
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
@@ -96,13 +105,18 @@ def main():
     tpr = rtx.tiles_per_rank(w, h, world)
     slab = torch.zeros(tpr * 192, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) if world > 1 else slab
+    gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
     image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
 
     def step():
         if world == 1:   # single GPU: the frame is written row-major in place
             return ctx.render_device(w, h, args.depth, 10, image.data_ptr())
         st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slab.data_ptr())
-        dist.all_gather_into_tensor(gathered, slab)
+        if gloo:
+            dist.all_gather_into_tensor(gathered_host, slab.cpu())
+            gathered.copy_(gathered_host)
+        else:
+            dist.all_gather_into_tensor(gathered, slab)
         torch.cuda.current_stream().synchronize()
         ctx.assemble_tiles(w, h, world, gathered.data_ptr(), image.data_ptr())
         return st
@@ -134,13 +148,19 @@ def main():
     elapsed = time.perf_counter() - t0
     total_traced = acc["traced"]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tr = torch.tensor([acc["traced"]], dtype=torch.float64, device=dev)
+        tr = torch.tensor([acc["traced"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         total_traced = float(tr.item())
 
+    sharded_equal = None
+    if world > 1 and rank == 0:   # outside the timed region: the assembled frame against a single-GPU frame
+        whole = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+        ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
+        torch.cuda.synchronize()
+        sharded_equal = bool(torch.equal(whole, image))
     if rank == 0:
         n_prims = flat.n_prims
         b_ray = synth.bytes_per_ray(n_prims)
@@ -176,8 +196,9 @@ def main():
             "config": {"workload": "synthetic %d-triangle tessellated height field + 4 point lights at %dx%d, depth %d, "
                                    "LBVH traversal, scene and BVH resident in HBM" % (flat.n_tris, w, h, args.depth),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth,
-                       "parallelism": "tile-sharded x%d" % world if world > 1 else "single GPU"},
+                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if world > 1 else "single GPU"},
             "rays_per_frame": total_traced / args.steps,
+            "sharded_frame_equals_single_gpu_frame": sharded_equal,
             "device_frame_ms_rank0": acc["render_ms"] / args.steps,
             "build_ms": build["build_ms"], "upload_ms": build["upload_ms"], "scene_broadcast_ms": bcast_ms,
             "bvh": {k: build[k] for k in ("n_nodes", "n_leaves", "max_depth", "key_bits", "uses_bvh")},
