@@ -149,7 +149,9 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^22)
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
  *   "trace_variant" 0 = one ray per lane, grid-stride (default), 1 = persistent wavefronts with lane refill
- *   "tune0".."tune3" traversal tuning: refill threshold, phase-vote weight (variant 1), workgroups per CU (1..8) */
+ *   "tune0".."tune3" traversal tuning: refill threshold, phase-vote weight (variant 1), workgroups per CU (1..8),
+ *                    primitives per leaf (1..8, at the next rtx_build)
+ *   "stamps"        1 = traversal kernels record per-wavefront time stamps (see rtx_debug_stamps); at the next rtx_build */
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
 
 /* ---- scene ---------------------------------------------------------------
@@ -215,6 +217,15 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world);
  * into a row-major [h][w][3] image (device memory). */
 int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
                        const uint8_t* d_slabs, uint8_t* d_rgb);
+
+/* Diagnostics (no counterpart in the reference): with the "stamps" option set, every
+ * wavefront of the last closest-hit launch (kind 0) or shadow launch (kind 1) has
+ * recorded 4 x u64: start and end on the 100 MHz constant clock, work units of 64
+ * rays taken, and its hardware placement (XCC_ID | SE_ID << 8 | CU_ID << 16).
+ * Copies up to `capacity` records of 4 u64 to `out` (host) and returns how many
+ * wavefront slots exist (0 when stamps are off). Slots of wavefronts that did
+ * not run hold zeros. */
+uint64_t rtx_debug_stamps(rtx_context* ctx, int kind, uint64_t* out, uint64_t capacity);
 
 /* The context's HIP stream as a void* (hipStream_t), for callers that order
  * their own work (collectives, events) against the library's kernels. */

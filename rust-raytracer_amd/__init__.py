@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_LIB", os.path.join(_HERE, "librtx_hip.so"))   # RTX_LIB: another build of the same library
 HOST_LIB_PATH = os.path.join(_HERE, "librstracer.so")
 CLI_PATH = os.path.join(_HERE, "rstracer")
 
@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
+    "rtx_debug_stamps",
 ]
 
 
@@ -145,6 +146,8 @@ def lib():
         L.rtx_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]
         L.rtx_stream.argtypes = [vp]
         L.rtx_stream.restype = vp
+        L.rtx_debug_stamps.argtypes = [vp, C.c_int, vp, u64]
+        L.rtx_debug_stamps.restype = u64
         _lib = L
     return _lib
 
@@ -323,6 +326,15 @@ class Context:
 
     def stream(self):
         return self._L.rtx_stream(self._h)
+
+    def debug_stamps(self, kind):
+        """Per-wavefront records (start, end on the 100 MHz clock, units, placement) of the last
+        closest-hit (kind 0) or shadow (kind 1) launch; needs set_option("stamps", 1) before build()."""
+        n = int(self._L.rtx_debug_stamps(self._h, kind, None, 0))
+        out = np.zeros((n, 4), np.uint64)
+        if n:
+            self._L.rtx_debug_stamps(self._h, kind, _ptr(out), n)
+        return out
 
     def intersect_batch(self, ori, dir, exhaustive=False):
         ori = np.ascontiguousarray(ori, np.float32).reshape(-1, 3)

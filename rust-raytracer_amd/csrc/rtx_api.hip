@@ -100,6 +100,18 @@ void rtx_destroy(rtx_context* ctx) {
 
 void* rtx_stream(rtx_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+uint64_t rtx_debug_stamps(rtx_context* ctx, int kind, uint64_t* out, uint64_t capacity) {
+    if (!ctx || !ctx->built || !ctx->ds.stamps || kind < 0 || kind > 2) return 0;
+    // kind 2 (diagnostic builds): per-unit records of the last closest-hit launch, 2^19 x 2 u64 read as 2^18 x 4
+    const uint64_t waves = ctx->ds.spill_stride / 64, count = (kind == 2) ? (1ull << 18) : waves;
+    const uint64_t n = std::min<uint64_t>(count, capacity);
+    if (out && n) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+        if (hipMemcpy(out, ctx->ds.stamps + (size_t)std::min(kind, 2) * waves * 4, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    }
+    return count;
+}
+
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return RTX_ERR_INVALID_ARG;
     const std::string k(key);
@@ -113,6 +125,9 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
+    } else if (k == "stamps") {
+        ctx->opt_stamps = value ? 1 : 0;
+        ctx->built = false;   // the stamp buffer is allocated by rtx_build
     } else if (k == "batch_pixels") {
         if (value < 64) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "batch_pixels must be at least 64");
         ctx->opt_batch_pixels = value;

@@ -593,7 +593,8 @@ int rtx_bvh_build(rtx_context* ctx) {
         return rtx_fail(ctx, RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
 
     PrimRec* recs = nullptr;
-    TRY(dev_alloc(ctx, ctx->build_allocs, &recs, n));
+    TRY(dev_alloc(ctx, ctx->build_allocs, &recs, (size_t)n + 1));   // one spare record: leaf fetches read 64 bytes (fetch_ref)
+    TRY_HIP(hipMemsetAsync(recs + n, 0, sizeof(PrimRec), st));
 
     // Scene bounds are needed in both modes (safe region of the padded tests).
     float4 *bmin = nullptr, *bmax = nullptr;
@@ -750,6 +751,14 @@ int rtx_bvh_build(rtx_context* ctx) {
         int* spill = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &spill, (size_t)s.spill_entries * s.spill_stride));
         s.spill = spill;
+        s.stamps = nullptr;
+        if (ctx->opt_stamps) {
+            unsigned long long* stamps = nullptr;
+            const size_t count = (size_t)2 * (s.spill_stride / 64) * 4 + ((size_t)2 << 19);   // + per-unit records of diagnostic builds
+            TRY(dev_alloc(ctx, ctx->build_allocs, &stamps, count));
+            TRY_HIP(hipMemsetAsync(stamps, 0, count * sizeof(unsigned long long), st));
+            s.stamps = stamps;
+        }
     }
     bs.uses_bvh = s.uses_bvh;
     TRY_HIP(hipEventRecord(ev1, st));

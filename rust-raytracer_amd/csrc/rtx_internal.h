@@ -87,6 +87,7 @@ struct DevScene {
     uint32_t spill_stride;      // thread slots = largest traversal grid * 256
     uint32_t spill_entries;
     int32_t tune[4];            // traversal tuning: [0] idle lanes that trigger a refill, [1] phase-vote weight (1/16ths)
+    unsigned long long* stamps; // diagnostics: [2 kinds][spill_stride / 64 wavefronts][4], or nullptr
 };
 
 // Work queue of rays: three arrays of 16-/8-byte elements so that every access
@@ -135,7 +136,8 @@ struct rtx_context {
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     int64_t opt_trace_variant = 0; // 0: one ray per lane, grid-stride; 1: persistent wavefronts with lane refill
     uint32_t num_cus = 256;
-    int32_t opt_tune[4] = {20, 8, 6, RTX_LEAF_MAX};
+    int32_t opt_tune[4] = {20, 8, 5, RTX_LEAF_MAX};
+    int64_t opt_stamps = 0;
 };
 
 // -- helpers shared by the translation units ---------------------------------

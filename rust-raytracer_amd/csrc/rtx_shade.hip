@@ -188,23 +188,48 @@ struct UnitQueue {
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-__global__ __launch_bounds__(RTX_BLOCK) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     TravStack st;
     st.set(lds, s);
     if (ctl->overflow) return;   // the batch is being abandoned
     const uint32_t n = ctl->n_rays[qi];
+    WaveStamp ws;
+    ws.begin(s, 0);
     UnitQueue uq;
     uq.init(&ctl->unit_head[0][0][0], n);
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        ++ws.units;
         const uint32_t i = unit * 64 + (threadIdx.x & 63);
-        if (i >= n) continue;
-        const float4 o4 = q.o[i], d4 = q.d[i];
-        int id = -1;
-        float t = 0.0f;
-        if (f2u(d4.w) & RTX_RAY_VALID) trace_closest(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
-        q.hit[i] = make_uint2((uint32_t)id, f2u(t));
+#ifdef RTX_COUNT_STEPS
+        st.steps = 0;
+        st.leaves = 0;
+        const unsigned long long unit_t0 = wall_clock64();
+#endif
+        if (i < n) {
+            const float4 o4 = q.o[i], d4 = q.d[i];
+            int id = -1;
+            float t = 0.0f;
+            if (f2u(d4.w) & RTX_RAY_VALID) trace_closest(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
+            q.hit[i] = make_uint2((uint32_t)id, f2u(t));
+        }
+#ifdef RTX_COUNT_STEPS
+        ws.add_steps(st.steps);
+        if (s.stamps) {   // per-unit record after the two wave tables: (start, duration | max steps << 24 | max leaves << 44)
+            uint32_t ms = st.steps + st.leaves, ml = st.steps + st.leaves;   // max and sum over lanes of the lane's iterations
+            for (int o = 32; o > 0; o >>= 1) {
+                ms = max(ms, (uint32_t)__shfl_xor(ms, o));
+                ml += (uint32_t)__shfl_xor(ml, o);
+            }
+            if ((threadIdx.x & 63) == 0 && unit < (1u << 19)) {
+                unsigned long long* ur = s.stamps + (size_t)2 * (s.spill_stride / 64) * 4 + (size_t)unit * 2;
+                ur[0] = unit_t0;
+                ur[1] = (wall_clock64() - unit_t0) | ((unsigned long long)ms << 24) | ((unsigned long long)ml << 44);
+            }
+        }
+#endif
     }
+    ws.end();
 }
 
 // Forward step 1: every hit becomes a shading node (shade_intersection is only
@@ -417,7 +442,7 @@ struct ShadowTask {
 };
 
 template <bool ANY, bool AREA>
-__global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     TravStack st;
     st.set(lds, s);
@@ -432,9 +457,12 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint3
     task.st = &st;
     task.rays = 0;
     const uint64_t total = min((uint64_t)task.nn * n_slots, (uint64_t)0xfffffff0u);
+    WaveStamp ws;
+    ws.begin(s, 1);
     UnitQueue uq;
     uq.init(&ctl->unit_head[1][0][0], total);
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        ++ws.units;
         const uint64_t k = (uint64_t)unit * 64 + (threadIdx.x & 63);
         if (k >= total) continue;
         V3 o, d;
@@ -451,6 +479,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow(DevScene s, Work wk, uint3
             }
         }
     }
+    ws.end();
     unsigned long long rays = task.rays;
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);

@@ -18,27 +18,33 @@
 #include "rtx_internal.h"
 
 #define RTX_BLOCK 256
+// Register budget of the traversal kernels, as waves per SIMD the compiler must make room for
+// (empty: the compiler's own choice).
+#ifndef RTX_TRAV_WAVES
+#define RTX_TRAV_OCCUPANCY
+#else
+#define RTX_TRAV_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RTX_TRAV_WAVES, RTX_TRAV_WAVES)))
+#endif
 
 RTX_D uint32_t f2u(float f) { return __float_as_uint(f); }
 RTX_D float u2f(uint32_t u) { return __uint_as_float(u); }
 
+// The primitive test of one record (already in registers); t is valid when true is returned.
+RTX_D bool record_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& t) {
+    if (f2u(q1.w) == 0u) return tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
+    return sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
+}
 // One candidate primitive against one ray; updates (best_t, best_id).
-RTX_D void test_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float& best_t, int& best_id) {
-    const float4 q0 = recs[idx].q0;
-    const float4 q1 = recs[idx].q1;
+RTX_D void test_quads(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& best_t, int& best_id) {
     const int id = (int)f2u(q0.w);
     float t;
-    bool hit;
-    if (f2u(q1.w) == 0u) {
-        const float4 q2 = recs[idx].q2;
-        hit = tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
-    } else {
-        hit = sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
-    }
-    if (hit && (t < best_t || (t == best_t && id < best_id))) {
+    if (record_hit(q0, q1, q2, o, d, t) && (t < best_t || (t == best_t && id < best_id))) {
         best_t = t;
         best_id = id;
     }
+}
+RTX_D void test_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float& best_t, int& best_id) {
+    test_quads(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, best_t, best_id);
 }
 
 // The loop of src/scene/mod.rs:186-199 over every record.
@@ -81,6 +87,41 @@ RTX_D bool box_hit(const RayBox& rb, float bx0, float by0, float bz0, float bx1,
     return (lo <= hi) && (hi >= 0.0f) && (lo <= best_t);
 }
 
+// Diagnostics: one record per wavefront slot of a traversal launch (see rtx_debug_stamps).
+struct WaveStamp {
+    unsigned long long* rec;
+    unsigned long long units;
+    unsigned long long step_sum = 0, step_max = 0;   // diagnostic build (RTX_COUNT_STEPS) only
+    // Adds one unit's per-lane step counts: sum over lanes and the slowest lane.
+    RTX_D void add_steps(uint32_t lane_steps) {
+        uint32_t sum = lane_steps, mx = lane_steps;
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+        }
+        step_sum += sum;
+        step_max += mx;
+    }
+    RTX_D void begin(const DevScene& s, int kind) {
+        rec = nullptr;
+        units = 0;
+        if (s.stamps && (threadIdx.x & 63) == 0) {
+            rec = s.stamps + ((size_t)kind * (s.spill_stride / 64) + (blockIdx.x * (RTX_BLOCK / 64) + (threadIdx.x >> 6))) * 4;
+            rec[0] = wall_clock64();
+        }
+    }
+    RTX_D void end() {
+        if (rec) {
+            uint32_t xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            rec[1] = wall_clock64();
+            rec[2] = units | (step_max << 16) | (step_sum << 40);
+            rec[3] = (xcc & 0xfu) | (((hw >> 13) & 0x7u) << 8) | (((hw >> 8) & 0xfu) << 16);
+        }
+    }
+};
+
 RTX_D bool in_safe_region(const DevScene& s, V3 o) {
     return fabsf(o.x - s.safe_c[0]) <= s.safe_r && fabsf(o.y - s.safe_c[1]) <= s.safe_r &&
            fabsf(o.z - s.safe_c[2]) <= s.safe_r;  // false for NaN origins
@@ -98,6 +139,10 @@ struct TravStack {
     int* base;
     int* spill;
     uint32_t spill_stride;
+#ifdef RTX_COUNT_STEPS
+    uint32_t steps = 0;   // diagnostic build: node steps of this lane
+    uint32_t leaves = 0;  // diagnostic build: primitive tests of this lane
+#endif
     RTX_D void set(int* lds, const DevScene& s) {
         base = lds + threadIdx.x;
         spill = s.spill + (blockIdx.x * RTX_BLOCK + threadIdx.x);
@@ -160,9 +205,11 @@ RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const Ra
 // stays conservative. Children that are hit are ordered near to far; the nearest
 // becomes the next node and the others are pushed, farthest first.
 // Returns the next reference, or `done` when nothing is hit and the stack is empty.
-RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& rb, V3 o, float limit, TravStack& st, int& sp,
-                     int done) {
-    const uint4 A = nodes[cur].a, B = nodes[cur].b, C = nodes[cur].c, D = nodes[cur].d;
+RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D, const RayBox& rb, V3 o, float limit,
+                     TravStack& st, int& sp, int done) {
+#ifdef RTX_COUNT_STEPS
+    ++st.steps;
+#endif
     const uint32_t meta = A.w;
     const float stx = u2f((meta & 0xffu) << 23), sty = u2f(((meta >> 8) & 0xffu) << 23), stz = u2f(((meta >> 16) & 0xffu) << 23);
     const float sx = stx * rb.inv.x, sy = sty * rb.inv.y, sz = stz * rb.inv.z;
@@ -211,7 +258,28 @@ RTX_D int node4_step(const BvhNode* __restrict__ nodes, int cur, const RayBox& r
     return st.get(--sp);
 }
 
+
 constexpr int kRefDone = 0x7fffffff;   // "no more work" reference (never a node index: fewer than 2^28 nodes exist)
+
+// What a traversal reference points at, fetched with ONE set of loads whatever its kind:
+// 64 bytes at nodes[ref] (inner node) or at recs[first] (leaf: the record's 48 bytes plus
+// 16 that are ignored; the record array is allocated one record longer than it is used).
+// A wavefront whose lanes sit on a mix of inner nodes and leaves then waits for memory once
+// per iteration, not once per kind.
+struct Fetched {
+    uint4 a, b, c, d;
+};
+RTX_D Fetched fetch_ref(const DevScene& s, int cur) {
+    const uint4* p = (cur >= 0) ? reinterpret_cast<const uint4*>(s.nodes + cur)
+                                : reinterpret_cast<const uint4*>(s.recs + (~(uint32_t)cur >> 3));
+    Fetched f;
+    f.a = p[0];
+    f.b = p[1];
+    f.c = p[2];
+    f.d = p[3];
+    return f;
+}
+RTX_D float4 as_f4(uint4 u) { return make_float4(u2f(u.x), u2f(u.y), u2f(u.z), u2f(u.w)); }
 
 // Closest hit through the BVH. Returns best_id = -1 on a miss.
 RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float& best_t, int& best_id) {
@@ -224,12 +292,17 @@ RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float
     const RayBox rb = make_raybox(s, o, d);
     int cur = 0, sp = 0;
     while (cur != kRefDone) {
+        const Fetched f = fetch_ref(s, cur);
         if (cur >= 0) {
-            cur = node4_step(s.nodes, cur, rb, o, best_t, st, sp, kRefDone);
+            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, best_t, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
+            test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
+            for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
+#ifdef RTX_COUNT_STEPS
+            st.leaves += cnt;
+#endif
             cur = (sp == 0) ? kRefDone : st.get(--sp);
         }
     }
@@ -248,18 +321,12 @@ RTX_D bool occluding_hit(V3 o, V3 d, float t, float dist_light) {
     const V3 p = o + vmult(d, t);                 // Intersection::point, intersection.rs:26-28
     return !(vdistance(o, p) > dist_light);       // lib.rs:123-127
 }
-RTX_D bool any_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float dist_light) {
-    const float4 q0 = recs[idx].q0;
-    const float4 q1 = recs[idx].q1;
+RTX_D bool any_quads(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist_light) {
     float t;
-    bool hit;
-    if (f2u(q1.w) == 0u) {
-        const float4 q2 = recs[idx].q2;
-        hit = tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
-    } else {
-        hit = sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
-    }
-    return hit && occluding_hit(o, d, t, dist_light);
+    return record_hit(q0, q1, q2, o, d, t) && occluding_hit(o, d, t, dist_light);
+}
+RTX_D bool any_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float dist_light) {
+    return any_quads(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, dist_light);
 }
 RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack& st) {
     if (!s.uses_bvh || !in_safe_region(s, o)) {
@@ -279,12 +346,14 @@ RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack&
     const RayBox rb = make_raybox(s, o, d);
     int cur = 0, sp = 0;
     while (cur != kRefDone) {
+        const Fetched f = fetch_ref(s, cur);
         if (cur >= 0) {
-            cur = node4_step(s.nodes, cur, rb, o, t_limit, st, sp, kRefDone);
+            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k)
+            if (any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light)) return true;
+            for (uint32_t k = 1; k < cnt; ++k)
                 if (any_record(s.recs, first + k, o, d, dist_light)) return true;
             cur = (sp == 0) ? kRefDone : st.get(--sp);
         }
