@@ -1,0 +1,192 @@
+// rtx_coop.h -- wavefront-cooperative traversal: the lanes of a wavefront share the
+// work of their slowest rays.
+//
+// One ray per lane is the fast way through the bulk of a launch, but a launch ends with
+// its slowest wavefront, and a wavefront's 64 rays end with their slowest ray: a ray
+// that grazes the surface visits ten times the nodes of its neighbours, one dependent
+// memory access after the other, while the other lanes (and, at the end of a launch,
+// most of the device) wait. A traversal stack, however, is a list of independent
+// subtrees. So the query runs in two phases:
+//   1. every lane traverses for its own ray, results in registers (as trace_bvh_closest /
+//      trace_any do), until fewer than `threshold` lanes of the wavefront still have work;
+//   2. the lanes publish their results to a per-ray slot in LDS and idle lanes take over
+//      subtrees from busy lanes: a lane with more than one pending entry gives its OLDEST
+//      stack entry (the largest subtree) to an idle lane, together with the ray (ds_bpermute).
+//      The helper traverses that subtree for the owner's ray; hits go to the owner's slot
+//      with a 64-bit LDS atomic min on (t bits, primitive id), which is exactly the
+//      order-independent rule `t < best || (t == best && id < best_id)`; every lane reads
+//      its ray's slot before each step, so all helpers cull with the best bound found so far.
+// Which lane tests a primitive does not change the primitive's t, and the minimum does not
+// depend on the order of its operands, so the result is the one the exhaustive loop gives.
+// Any-hit queries share a flag instead of a key: the first occluder found by any lane ends
+// the work of all lanes on that ray.
+#pragma once
+#include "rtx_traverse.h"
+
+struct CoopLds {
+    unsigned long long slot[RTX_BLOCK];   // per lane's ray: closest: (t bits << 32) | id; any-hit: 0 = occluded, 1 = not
+    int pair[RTX_BLOCK];                  // per wavefront: donor lane by rank
+};
+
+constexpr unsigned long long kCoopMiss = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;   // t = +inf, no primitive
+
+// All 64 lanes of a wavefront must call this together (`active` = the lane has a ray).
+// Closest (ANY = false): out_id = primitive id or -1, out_t = its t.
+// Any-hit (ANY = true):  out_id = 1 when some primitive occludes the light at distance dist_light
+//                        (dist_light < 0: any hit occludes), else 0.
+template <bool ANY>
+RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_light, TravStack& st, CoopLds& L, int threshold,
+                      float& out_t, int& out_id) {
+    const int lane = threadIdx.x & 63;
+    float best_t = __builtin_inff();
+    int best_id = ANY ? 0 : 0x7fffffff;
+    int cur = kRefDone, sp = 0;
+    if (active) {
+        if (!s.uses_bvh || !in_safe_region(s, o)) {   // every primitive, as the reference loop does
+            if (ANY) {
+                for (uint32_t i = 0; i < s.n_prims; ++i)
+                    if (any_record(s.recs, i, o, d, dist_light)) { best_id = 1; break; }
+            } else {
+                for (uint32_t i = 0; i < s.n_prims; ++i) test_record(s.recs, i, o, d, best_t, best_id);
+            }
+        } else {
+            cur = 0;
+        }
+    }
+    // any-hit: boxes beyond the light never hold an occluder (see trace_any)
+    float t_limit = __builtin_inff();
+    if (ANY && dist_light >= 0.0f) {
+        const float len = vlength(d);
+        const float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+        if (len > 0.0f) t_limit = ((dist_light + 4e-6f * m) / len) * 1.0001f + 1e-6f;
+    }
+    RayBox rb = make_raybox(s, o, d);
+
+    // ---- phase 1: one ray per lane ----
+    uint64_t busy;
+    for (;;) {
+        busy = __ballot(cur != kRefDone);
+        if (busy == 0 || __popcll(busy) < threshold) break;
+        if (cur != kRefDone) {
+            const Fetched f = fetch_ref(s, cur);
+            if (cur >= 0) {
+                cur = node4_step(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
+            } else {
+                const uint32_t leaf = ~(uint32_t)cur;
+                const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+                if (ANY) {
+                    bool occ = any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
+                    for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record(s.recs, first + k, o, d, dist_light);
+                    if (occ) {
+                        best_id = 1;
+                        sp = 0;
+                    }
+                } else {
+                    test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
+                    for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
+                }
+#ifdef RTX_COUNT_STEPS
+                st.leaves += cnt;
+#endif
+                cur = (sp == 0) ? kRefDone : st.get(--sp);
+            }
+        }
+    }
+    if (busy == 0) {   // wave-uniform
+        out_t = best_t;
+        out_id = ANY ? best_id : (best_id == 0x7fffffff ? -1 : best_id);
+        return;
+    }
+
+    // ---- phase 2: idle lanes take subtrees from busy lanes ----
+    volatile unsigned long long* slot = L.slot + (threadIdx.x & ~63u);   // this wavefront's 64 slots
+    volatile int* pair = L.pair + (threadIdx.x & ~63u);
+    slot[lane] = ANY ? (best_id ? 0ull : 1ull) : (((unsigned long long)f2u(best_t) << 32) | (uint32_t)best_id);
+    int owner = lane, bot = 0;
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (;;) {
+        const bool has = cur != kRefDone;
+        busy = __ballot(has);
+        if (busy == 0) break;
+        const bool can_give = has && sp > bot;
+        const uint64_t don = __ballot(can_give);
+        if (~busy != 0 && don != 0) {   // wave-uniform
+            const int np = min(__popcll(~busy), __popcll(don));
+            const int rd = __popcll(don & lt), ri = __popcll(~busy & lt);
+            const bool giver = can_give && rd < np, taker = !has && ri < np;
+            if (giver) pair[rd] = lane;
+            __builtin_amdgcn_wave_barrier();
+            const int src = taker ? pair[ri] : lane;
+            __builtin_amdgcn_wave_barrier();
+            const int bref = can_give ? st.get(bot) : 0;
+            const int t_ref = __shfl(bref, src), t_owner = __shfl(owner, src);
+            const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
+            const float dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
+            const float i0 = __shfl(rb.inv.x, src), i1 = __shfl(rb.inv.y, src), i2 = __shfl(rb.inv.z, src);
+            const float m0 = __shfl(rb.oim.x, src), m1 = __shfl(rb.oim.y, src), m2 = __shfl(rb.oim.z, src);
+            const float p0 = __shfl(rb.oip.x, src), p1 = __shfl(rb.oip.y, src), p2 = __shfl(rb.oip.z, src);
+            const float tl = ANY ? __shfl(t_limit, src) : 0.0f, dl = ANY ? __shfl(dist_light, src) : 0.0f;
+            if (giver) ++bot;
+            if (taker) {
+                cur = t_ref;
+                owner = t_owner;
+                o = v3(ox, oy, oz);
+                d = v3(dx, dy, dz);
+                rb.inv = v3(i0, i1, i2);
+                rb.oim = v3(m0, m1, m2);
+                rb.oip = v3(p0, p1, p2);
+                if (ANY) {
+                    t_limit = tl;
+                    dist_light = dl;
+                }
+                sp = bot = 0;
+            }
+        }
+        if (cur != kRefDone) {
+            const unsigned long long key = slot[owner];
+            if (ANY && key == 0ull) {   // another lane found an occluder for this ray
+                cur = kRefDone;
+                sp = bot;
+            } else {
+                const Fetched f = fetch_ref(s, cur);
+                if (cur >= 0) {
+                    cur = node4_step(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
+                } else {
+                    const uint32_t leaf = ~(uint32_t)cur;
+                    const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+                    if (ANY) {
+                        bool occ = any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
+                        for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record(s.recs, first + k, o, d, dist_light);
+                        if (occ) {
+                            slot[owner] = 0ull;
+                            sp = bot;
+                        }
+                    } else {
+                        float bt = u2f((uint32_t)(key >> 32));
+                        int bi = (int)(uint32_t)key;
+                        const float bt0 = bt;
+                        const int bi0 = bi;
+                        test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, bt, bi);
+                        for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, bt, bi);
+                        if (bt != bt0 || bi != bi0)
+                            atomicMin((unsigned long long*)&L.slot[(threadIdx.x & ~63u) + owner],
+                                      ((unsigned long long)f2u(bt) << 32) | (uint32_t)bi);
+                    }
+#ifdef RTX_COUNT_STEPS
+                    st.leaves += cnt;
+#endif
+                    cur = (sp == bot) ? kRefDone : st.get(--sp);
+                }
+            }
+        }
+    }
+    const unsigned long long key = slot[lane];
+    if (ANY) {
+        out_t = 0.0f;
+        out_id = (key == 0ull) ? 1 : 0;
+    } else {
+        out_t = u2f((uint32_t)(key >> 32));
+        const int id = (int)(uint32_t)key;
+        out_id = (id == 0x7fffffff) ? -1 : id;
+    }
+}

@@ -136,7 +136,7 @@ struct rtx_context {
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     int64_t opt_trace_variant = 0; // 0: one ray per lane, grid-stride; 1: persistent wavefronts with lane refill
     uint32_t num_cus = 256;
-    int32_t opt_tune[4] = {20, 8, 5, RTX_LEAF_MAX};
+    int32_t opt_tune[4] = {48, 8, 4, RTX_LEAF_MAX};
     int64_t opt_stamps = 0;
 };
 

@@ -76,7 +76,7 @@ RTX_D void trav_begin(const DevScene& s, Trav& tr, V3 o, V3 d, float dist_light)
 }
 
 RTX_D void trav_node_step(const BvhNode* __restrict__ nodes, Trav& tr, TravStack& st) {
-    tr.cur = node4_step(nodes[tr.cur].a, nodes[tr.cur].b, nodes[tr.cur].c, nodes[tr.cur].d, tr.rb, tr.o, tr.best_t, st, tr.sp, kTravDone);
+    tr.cur = node4_step(nodes[tr.cur].a, nodes[tr.cur].b, nodes[tr.cur].c, nodes[tr.cur].d, tr.rb, tr.o, tr.best_t, st, tr.sp, 0, kTravDone);
 }
 
 template <bool ANY>

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <utility>
 
+#include "rtx_coop.h"
 #include "rtx_persist.h"
 #include "rtx_shading.h"
 
@@ -190,6 +191,7 @@ struct UnitQueue {
 // one ray per lane (variant 0, the default).
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    __shared__ CoopLds coop;
     TravStack st;
     st.set(lds, s);
     if (ctl->overflow) return;   // the batch is being abandoned
@@ -206,16 +208,19 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         st.leaves = 0;
         const unsigned long long unit_t0 = wall_clock64();
 #endif
+        float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
         if (i < n) {
-            const float4 o4 = q.o[i], d4 = q.d[i];
-            int id = -1;
-            float t = 0.0f;
-            if (f2u(d4.w) & RTX_RAY_VALID) trace_closest(s, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), st, t, id);
-            q.hit[i] = make_uint2((uint32_t)id, f2u(t));
+            o4 = q.o[i];
+            d4 = q.d[i];
         }
+        int id = -1;
+        float t = 0.0f;
+        coop_trace<false>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
+                          s.tune[0], t, id);
+        if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
 #ifdef RTX_COUNT_STEPS
         ws.add_steps(st.steps);
-        if (s.stamps) {   // per-unit record after the two wave tables: (start, duration | max steps << 24 | max leaves << 44)
+        if (s.stamps) {   // per-unit record after the two wave tables: (start, duration | max iterations << 24 | sum << 44)
             uint32_t ms = st.steps + st.leaves, ml = st.steps + st.leaves;   // max and sum over lanes of the lane's iterations
             for (int o = 32; o > 0; o >>= 1) {
                 ms = max(ms, (uint32_t)__shfl_xor(ms, o));
@@ -444,6 +449,7 @@ struct ShadowTask {
 template <bool ANY, bool AREA>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    __shared__ CoopLds coop;
     TravStack st;
     st.set(lds, s);
     Ctl* ctl = wk.ctl;
@@ -464,18 +470,17 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
         ++ws.units;
         const uint64_t k = (uint64_t)unit * 64 + (threadIdx.x & 63);
-        if (k >= total) continue;
-        V3 o, d;
-        float dl;
-        if (!task.start((uint32_t)k, o, d, dl)) continue;
+        V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
+        float dl = -1.0f, t;
+        int id;
+        bool live = k < total && task.start((uint32_t)k, o, d, dl);
         if (ANY) {
-            task.finish_any(trace_any(s, o, d, dl, st));
+            coop_trace<true>(s, live, o, d, dl, st, coop, s.tune[0], t, id);
+            if (live) task.finish_any(id != 0);
         } else {
-            for (;;) {
-                float t;
-                int id;
-                trace_closest(s, o, d, st, t, id);
-                if (!task.finish_closest(id, t, o, d)) break;
+            while (__ballot(live)) {   // all lanes stay in the loop: the traversal is cooperative
+                coop_trace<false>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+                if (live) live = task.finish_closest(id, t, o, d);
             }
         }
     }

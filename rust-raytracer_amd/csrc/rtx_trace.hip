@@ -2,7 +2,7 @@
 // for caller-supplied rays: one ray per lane, grid-stride over a device-sized grid.
 #include <algorithm>
 
-#include "rtx_traverse.h"
+#include "rtx_coop.h"
 
 namespace {
 
@@ -10,17 +10,29 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n,
                                                          const float* __restrict__ dir3, int32_t* __restrict__ prim,
                                                          float* __restrict__ tout, int exhaustive) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
+    __shared__ CoopLds coop;
     TravStack st;
     st.set(lds, s);
-    for (uint64_t i = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RTX_BLOCK) {
-        const V3 o = v3(ori3[i * 3], ori3[i * 3 + 1], ori3[i * 3 + 2]);
-        const V3 d = v3(dir3[i * 3], dir3[i * 3 + 1], dir3[i * 3 + 2]);
-        float t;
-        int id;
-        if (exhaustive || !s.uses_bvh) trace_exhaustive(s, o, d, t, id);
-        else trace_bvh_closest(s, o, d, st, t, id);
-        prim[i] = id;
-        if (tout) tout[i] = (id >= 0) ? t : 0.0f;
+    // block-uniform trip count: the BVH query is cooperative inside a wavefront
+    for (uint64_t base = (uint64_t)blockIdx.x * RTX_BLOCK; base < n; base += (uint64_t)gridDim.x * RTX_BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        const bool live = i < n;
+        V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
+        if (live) {
+            o = v3(ori3[i * 3], ori3[i * 3 + 1], ori3[i * 3 + 2]);
+            d = v3(dir3[i * 3], dir3[i * 3 + 1], dir3[i * 3 + 2]);
+        }
+        float t = 0.0f;
+        int id = -1;
+        if (exhaustive || !s.uses_bvh) {
+            if (live) trace_exhaustive(s, o, d, t, id);
+        } else {
+            coop_trace<false>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+        }
+        if (live) {
+            prim[i] = id;
+            if (tout) tout[i] = (id >= 0) ? t : 0.0f;
+        }
     }
 }
 

@@ -205,8 +205,9 @@ RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const Ra
 // stays conservative. Children that are hit are ordered near to far; the nearest
 // becomes the next node and the others are pushed, farthest first.
 // Returns the next reference, or `done` when nothing is hit and the stack is empty.
+// The lane's stack holds entries [bot, sp): bot > 0 once the oldest entries were given away (rtx_coop.h).
 RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D, const RayBox& rb, V3 o, float limit,
-                     TravStack& st, int& sp, int done) {
+                     TravStack& st, int& sp, int bot, int done) {
 #ifdef RTX_COUNT_STEPS
     ++st.steps;
 #endif
@@ -254,7 +255,7 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
     if (t[2] < inf) st.put(sp++, r[2]);
     if (t[1] < inf) st.put(sp++, r[1]);
     if (t[0] < inf) return r[0];
-    if (sp == 0) return done;
+    if (sp == bot) return done;
     return st.get(--sp);
 }
 
@@ -294,7 +295,7 @@ RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float
     while (cur != kRefDone) {
         const Fetched f = fetch_ref(s, cur);
         if (cur >= 0) {
-            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, best_t, st, sp, kRefDone);
+            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, best_t, st, sp, 0, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
@@ -348,7 +349,7 @@ RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack&
     while (cur != kRefDone) {
         const Fetched f = fetch_ref(s, cur);
         if (cur >= 0) {
-            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, kRefDone);
+            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, 0, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
