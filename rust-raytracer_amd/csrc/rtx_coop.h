@@ -64,13 +64,16 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
 
     // ---- phase 1: one ray per lane ----
     uint64_t busy;
+#ifdef RTX_COOP_ONLY
+    busy = __ballot(cur != kRefDone);
+#else
     for (;;) {
         busy = __ballot(cur != kRefDone);
         if (busy == 0 || __popcll(busy) < threshold) break;
         if (cur != kRefDone) {
             const Fetched f = fetch_ref(s, cur);
             if (cur >= 0) {
-                cur = node4_step(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
+                cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
             } else {
                 const uint32_t leaf = ~(uint32_t)cur;
                 const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
@@ -92,6 +95,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             }
         }
     }
+#endif
     if (busy == 0) {   // wave-uniform
         out_t = best_t;
         out_id = ANY ? best_id : (best_id == 0x7fffffff ? -1 : best_id);
@@ -150,7 +154,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             } else {
                 const Fetched f = fetch_ref(s, cur);
                 if (cur >= 0) {
-                    cur = node4_step(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
+                    cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
                 } else {
                     const uint32_t leaf = ~(uint32_t)cur;
                     const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;

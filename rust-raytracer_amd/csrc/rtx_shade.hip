@@ -117,8 +117,10 @@ RTX_D void wave_count(unsigned long long* counter, bool flag) {
     if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, (unsigned long long)__popcll(m));
 }
 
-__global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
+// first: the first batch of a frame starts the frame's counters from zero.
+__global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback, int first) {
     for (int k = 0; k < 7; ++k) {
+        if (first) ctl->stat[k] = 0;
         if (rollback) ctl->stat[k] = ctl->saved[k];
         else ctl->saved[k] = ctl->stat[k];
     }
@@ -134,21 +136,36 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback) {
 
 // Primary rays of one batch. Ray g of a rank lives in tile (g / 64) of that rank's
 // interleaved tile list and is pixel (g % 8, g / 8 % 8) of the tile: one
-// wavefront = one 8x8-pixel tile, so its 64 rays are coherent.
-__global__ __launch_bounds__(RTX_BLOCK) void k_raygen(CamSetup cam, Work wk, uint64_t first, uint32_t n, uint32_t rank,
-                                                      uint32_t world, uint32_t tiles_x, uint32_t n_tiles) {
+// wavefront = one 8x8-pixel tile, so its 64 rays are coherent. The level-0 kernels
+// compute the ray from its index (same operations, same bits) instead of reading it
+// from a queue; `enabled` = 0 for deeper levels.
+struct PrimaryGen {
+    CamSetup cam;
+    uint64_t first;
+    uint32_t rank, world, tiles_x, n_tiles;
+    uint32_t enabled;
+};
+RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4) {
+    const CamSetup& cam = pg.cam;
+    const uint64_t g = pg.first + i;
+    const uint64_t tile = (g >> 6) * pg.world + pg.rank;
+    const uint32_t lane = (uint32_t)(g & 63);
+    const uint32_t x = (uint32_t)(tile % pg.tiles_x) * RTX_TILE + (lane & 7u);
+    const uint32_t y = (uint32_t)(tile / pg.tiles_x) * RTX_TILE + (lane >> 3);
+    const bool valid = tile < pg.n_tiles && x < cam.w && y < cam.h;
+    V3 d = v3(0.0f, 0.0f, 0.0f);
+    if (valid) d = compute_ray_dir(cam, (float)x, (float)(cam.h - y - 1));   // lib.rs:263
+    o4 = make_float4(cam.cam_pos.x, cam.cam_pos.y, cam.cam_pos.z, u2f((uint32_t)g));
+    d4 = make_float4(d.x, d.y, d.z, u2f(valid ? (RTX_RAY_VALID | RTX_RAY_VACUUM) : 0u));
+}
+// The same rays written to queue 0 (rtx_primary_hits reads them back).
+__global__ __launch_bounds__(RTX_BLOCK) void k_raygen(PrimaryGen pg, Work wk, uint32_t n) {
     const uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (i < n) {
-        const uint64_t g = first + i;
-        const uint64_t tile = (g >> 6) * world + rank;
-        const uint32_t lane = (uint32_t)(g & 63);
-        const uint32_t x = (uint32_t)(tile % tiles_x) * RTX_TILE + (lane & 7u);
-        const uint32_t y = (uint32_t)(tile / tiles_x) * RTX_TILE + (lane >> 3);
-        const bool valid = tile < n_tiles && x < cam.w && y < cam.h;
-        V3 d = v3(0.0f, 0.0f, 0.0f);
-        if (valid) d = compute_ray_dir(cam, (float)x, (float)(cam.h - y - 1));   // lib.rs:263
-        wk.q[0].o[i] = make_float4(cam.cam_pos.x, cam.cam_pos.y, cam.cam_pos.z, u2f((uint32_t)g));
-        wk.q[0].d[i] = make_float4(d.x, d.y, d.z, u2f(valid ? (RTX_RAY_VALID | RTX_RAY_VACUUM) : 0u));
+        float4 o4, d4;
+        primary_ray(pg, i, o4, d4);
+        wk.q[0].o[i] = o4;
+        wk.q[0].d[i] = d4;
     }
 }
 
@@ -189,7 +206,7 @@ struct UnitQueue {
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
     TravStack st;
@@ -210,8 +227,12 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
 #endif
         float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
         if (i < n) {
-            o4 = q.o[i];
-            d4 = q.d[i];
+            if (pg.enabled) {
+                primary_ray(pg, i, o4, d4);
+            } else {
+                o4 = q.o[i];
+                d4 = q.d[i];
+            }
         }
         int id = -1;
         float t = 0.0f;
@@ -237,13 +258,46 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
     ws.end();
 }
 
+// Where level-0 colours go: the rank's packed tile slab (pixel slot = ray index) or, for a
+// single-GPU frame, straight into the row-major image.
+struct OutMap {
+    uint8_t* rgb;
+    uint32_t direct_w;   // 0: tile slab; otherwise the image width (row-major output)
+    uint32_t tiles_x;
+    RTX_D size_t pixel(uint32_t link) const {
+        if (!direct_w) return link;
+        const uint32_t tile = link >> 6, lane = link & 63u;
+        const uint32_t x = (tile % tiles_x) * RTX_TILE + (lane & 7u), y = (tile / tiles_x) * RTX_TILE + (lane >> 3);
+        return (size_t)y * direct_w + x;
+    }
+};
+// `direct + ambient + reflective + refractive` (lib.rs:254) with reflective = ks * child
+// (lib.rs:234) and refractive = child.mult(kt) (lib.rs:244-245); `local` = direct + ambient.
+// A missing child is a zero colour, which yields the same value as Color::new().
+RTX_D Col combine_colour(const DevScene& s, uint32_t mat0, Col local, Col child_refl, Col child_refr) {
+    const rtx_material* m = material_or_null(s, mat0);
+    const Col ks = m ? col_raw(m->specular) : col_new();
+    const float kt = m ? m->transparency : 0.0f;
+    const Col reflective = ks * child_refl;
+    const Col refractive = col_mult(child_refr, kt);
+    return (local + reflective) + refractive;
+}
+RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as_pixel, material.rs:57-63
+    uint8_t* px = out.rgb + out.pixel(link) * 3;
+    px[0] = col_u8(c.r);
+    px[1] = col_u8(c.g);
+    px[2] = col_u8(c.b);
+}
+
 // Forward step 1: every hit becomes a shading node (shade_intersection is only
 // entered for hits: lib.rs:264-271, 232-236, 243-247). A workgroup takes a chunk of
 // 256 * kShadeItems consecutive rays, counts its hits first and reserves their node
 // slots with ONE atomic, so the node order follows the ray order inside a chunk and
 // the global counter sees ~n/2048 atomics instead of one per wavefront.
 constexpr int kShadeItems = 8;
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm) {
+// Level 0 with row-major output also paints the pixels of primary rays that missed
+// (bmp::Image::new's black), so the image needs no clearing pass.
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm, PrimaryGen pg, OutMap out) {
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
     __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
@@ -286,13 +340,30 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             }
             const uint32_t node = run + before + pre[k];
             run += row;
-            if ((int)hit[k].x < 0) continue;
+            if ((int)hit[k].x < 0) {
+                const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
+                if (pg.enabled && out.direct_w && i < n) {
+                    float4 o4, d4;
+                    primary_ray(pg, i, o4, d4);
+                    if (f2u(d4.w) & RTX_RAY_VALID) {
+                        uint8_t* px = out.rgb + out.pixel(f2u(o4.w)) * 3;
+                        px[0] = px[1] = px[2] = 0;
+                    }
+                }
+                continue;
+            }
             if (node >= wk.cap_rays || pool_base + node >= wk.cap_pool) {
                 ctl->overflow = 1;
                 continue;
             }
             const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
-            const float4 o4 = q.o[i], d4 = q.d[i];
+            float4 o4, d4;
+            if (pg.enabled) {
+                primary_ray(pg, i, o4, d4);
+            } else {
+                o4 = q.o[i];
+                d4 = q.d[i];
+            }
             const V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
             const HitGeom g = hit_geometry(s, (int)hit[k].x, o, d, u2f(hit[k].y), true);
             panic |= g.panic;
@@ -560,11 +631,15 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uin
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
 }
 
-// Forward step 3: local colour and children.
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples) {
+// Forward step 3: local colour and children. `finalize`: the frame has a single level (no
+// material reflects or refracts, or depth 1), so a node's colour is final: it goes straight to
+// the image and the level bookkeeping of k_next_level is done here.
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples,
+                                                       OutMap out, int finalize) {
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     const uint32_t nn = ctl->n_nodes;
+    if (finalize && blockIdx.x == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
     const RayQueue q = wk.q[qo];
     const uint32_t stride = gridDim.x * RTX_BLOCK;
     const bool spawn = node_depth > 1;   // children are shaded at node_depth - 1
@@ -603,9 +678,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
                 }
             }
             const Col local = direct_light + ambient_light;           // first '+' of lib.rs:254
-            wk.pL[slot] = make_float4(local.r, local.g, local.b, u2f(mat0));
-            wk.pC0[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            wk.pC1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (finalize) {
+                store_pixel(out, wk.pLink[slot], combine_colour(s, mat0, local, col_new(), col_new()));
+            } else {
+                wk.pL[slot] = make_float4(local.r, local.g, local.b, u2f(mat0));
+                wk.pC0[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                wk.pC1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
             if (col_scalar(ks) > 0.0f) {                              // lib.rs:230
                 refl = true;
                 reflective_ray(dir, point, normal, ro0, rd0);
@@ -645,40 +724,18 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
     if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
 }
 
-// Backward: `direct + ambient + reflective + refractive` (lib.rs:254) with
-// reflective = ks * child (lib.rs:234) and refractive = child.mult(kt) (lib.rs:244-245).
-// A missing child left its slot at zero, which yields the same value as Color::new().
-// Where level-0 colours go: the rank's packed tile slab (pixel slot = ray index) or, for a
-// single-GPU frame, straight into the row-major image.
-struct OutMap {
-    uint8_t* rgb;
-    uint32_t direct_w;   // 0: tile slab; otherwise the image width (row-major output)
-    uint32_t tiles_x;
-};
+// Backward pass, one level per launch from the deepest up: a node's final colour goes into
+// its parent's child slot, or, at level 0, into the image.
 __global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint32_t level, OutMap out) {
     const Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     const uint32_t lo = ctl->level_start[level], hi = ctl->level_start[level + 1];
     for (uint32_t slot = lo + blockIdx.x * RTX_BLOCK + threadIdx.x; slot < hi; slot += gridDim.x * RTX_BLOCK) {
         const float4 l4 = wk.pL[slot], c0 = wk.pC0[slot], c1 = wk.pC1[slot];
-        const rtx_material* m = material_or_null(s, f2u(l4.w));
-        const Col ks = m ? col_raw(m->specular) : col_new();
-        const float kt = m ? m->transparency : 0.0f;
-        const Col reflective = ks * Col{c0.x, c0.y, c0.z};
-        const Col refractive = col_mult(Col{c1.x, c1.y, c1.z}, kt);
-        const Col c = (Col{l4.x, l4.y, l4.z} + reflective) + refractive;
+        const Col c = combine_colour(s, f2u(l4.w), Col{l4.x, l4.y, l4.z}, Col{c0.x, c0.y, c0.z}, Col{c1.x, c1.y, c1.z});
         const uint32_t link = wk.pLink[slot];
         if (level == 0) {
-            size_t pixel = link;
-            if (out.direct_w) {
-                const uint32_t tile = link >> 6, lane = link & 63u;
-                const uint32_t x = (tile % out.tiles_x) * RTX_TILE + (lane & 7u), y = (tile / out.tiles_x) * RTX_TILE + (lane >> 3);
-                pixel = (size_t)y * out.direct_w + x;
-            }
-            uint8_t* px = out.rgb + pixel * 3;   // Color::as_pixel, material.rs:57-63
-            px[0] = col_u8(c.r);
-            px[1] = col_u8(c.g);
-            px[2] = col_u8(c.b);
+            store_pixel(out, link, c);
         } else {
             const uint32_t parent = link & 0x7fffffffu;
             float4* dst = (link >> 31) ? wk.pC1 : wk.pC0;
@@ -770,6 +827,15 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
     return RTX_OK;
 }
 
+// Waits for the stream by polling: a blocking hipStreamSynchronize wakes up tens of
+// microseconds after the stream has drained, which is a large part of a sub-millisecond frame.
+inline hipError_t wait_stream(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+}
+
 inline uint32_t blocks_for(uint64_t n, uint32_t cap) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + RTX_BLOCK - 1) / RTX_BLOCK, cap));
 }
@@ -802,11 +868,13 @@ PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
     const uint32_t blocks = trav_blocks(ctx, ((chunks + 3) / 4) * RTX_BLOCK);
     return PersistGrid{blocks, blocks * 4 * kChunk};
 }
-void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, hipStream_t st) {
+void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, hipStream_t st) {
     const DevScene& s = ctx->ds;
     if (ctx->opt_trace_variant == 0) {
-        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi);
+        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg);
     } else {
+        if (pg.enabled)   // the persistent variant reads its rays from the queue
+            hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_upper, 1u << 22)), dim3(RTX_BLOCK), 0, st, pg, wk, n_upper);
         const PersistGrid g = persist_grid(ctx, n_upper);
         hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);
     }
@@ -863,7 +931,12 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     }
     // direct: d_rgb_tiles is a row-major [h][w][3] image (single GPU only); otherwise the rank's tile slab
     if (direct && world != 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "row-major output needs world == 1");
-    RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
+    // Without reflective or refractive materials no child is ever spawned: one level is exact.
+    const uint32_t levels = ctx->has_secondary ? depth : std::min<uint32_t>(depth, 1);
+    // Row-major frames are painted completely by the kernels (k_shade_a paints the misses);
+    // tile slabs have padding that no ray covers, and a depth-0 frame shades nothing.
+    if (!direct || levels == 0)
+        RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
     const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x};
     if (!ctx->pinned) {
         void* p = nullptr;
@@ -884,11 +957,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     if (rc != RTX_OK) return rc;
     wk.n_samples = n_samples;
     wk.area_off = (s.n_area_lights && samples == 0) ? 1u : 0u;
-    RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
 
     const CamSetup cam = make_cam(ctx->camera, w, h);
-    // Without reflective or refractive materials no child is ever spawned: one level is exact.
-    const uint32_t levels = ctx->has_secondary ? depth : std::min<uint32_t>(depth, 1);
+    const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
     const bool any_shadow = !s.has_transparent;
     EventPool ev{ctx};
     hipEvent_t f0 = ev.next(), f1 = ev.next();
@@ -901,23 +972,25 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     for (uint64_t first = 0; first < rays_local;) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(cur_batch, rays_local - first);
         ++n_batches;
-        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback);
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback, n_batches == 1 ? 1 : 0);
         rollback = 0;
-        hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, cam, wk, first, n, rank, world,
-                           tiles_x, (uint32_t)n_tiles);
+        const PrimaryGen gen{cam, first, rank, world, tiles_x, (uint32_t)n_tiles, 1u};   // level 0: rays come from their index
+        PrimaryGen no_gen = gen;
+        no_gen.enabled = 0;
         int qi = 0;
         uint32_t n_rays = n, levels_done = 0;
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
-            launch_closest(ctx, wk, 0, n_rays, st);
+            launch_closest(ctx, wk, 0, n_rays, gen, st);
         for (uint32_t level = 0; level < levels; ++level) {
             hipEvent_t a = ev.next(), b = ev.next();
             if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
             RTX_HIP(ctx, hipEventRecord(a, st));
-            launch_closest(ctx, wk, qi, n_rays, st);
+            const PrimaryGen& pg = (level == 0) ? gen : no_gen;
+            launch_closest(ctx, wk, qi, n_rays, pg, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
-                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w});
+                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -927,12 +1000,14 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 RTX_HIP(ctx, hipEventRecord(d, st));
                 shadow_events.emplace_back(c, d);
             }
-            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples);
+            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
+                               out_map, single_level ? 1 : 0);
+            if (single_level) break;
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
             levels_done = level + 1;
             if (level + 1 < levels) {
                 RTX_HIP(ctx, hipMemcpyAsync(host_next, &wk.ctl->n_rays[qi ^ 1], 4, hipMemcpyDeviceToHost, st));
-                RTX_HIP(ctx, hipStreamSynchronize(st));
+                RTX_HIP(ctx, wait_stream(st));
                 const uint32_t next = *host_next;
                 if (next == 0) break;
                 n_rays = std::min(next, wk.cap_rays);
@@ -948,7 +1023,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         const bool last_batch = first + n >= rays_local;
         RTX_HIP(ctx, hipMemcpyAsync(host_ctl, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
         if (last_batch) RTX_HIP(ctx, hipEventRecord(f1, st));
-        RTX_HIP(ctx, hipStreamSynchronize(st));
+        RTX_HIP(ctx, wait_stream(st));
         if (host_ctl->overflow) {
             // The ray tree of this batch outgrew the queues: render the same pixels again in
             // smaller batches (the workspace keeps its size, so relative capacity doubles).
@@ -1009,14 +1084,13 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
     Work wk;
     int rc = ensure_workspace(ctx, batch, ctx->ds.n_lights, &wk);
     if (rc != RTX_OK) return rc;
-    RTX_HIP(ctx, hipMemsetAsync(wk.ctl, 0, sizeof(Ctl), st));
     const CamSetup cam = make_cam(ctx->camera, w, h);
     for (uint64_t first = 0; first < rays; first += batch) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(batch, rays - first);
-        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0);
-        hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, cam, wk, first, n, 0u, 1u, tiles_x,
-                           (uint32_t)n_tiles);
-        launch_closest(ctx, wk, 0, n, st);
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0, 1);
+        const PrimaryGen gen{cam, first, 0u, 1u, tiles_x, (uint32_t)n_tiles, 1u};
+        hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, gen, wk, n);   // k_primary_out reads the directions
+        launch_closest(ctx, wk, 0, n, gen, st);
         hipLaunchKernelGGL(k_primary_out, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, wk.q[0], first, n, w, h, tiles_x,
                            d_prim, d_t, d_dir);
     }

@@ -192,7 +192,8 @@ RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const Ra
         }
         const float lo = fmaxf(fmaxf(nx, ny), nz);
         const float hi = fminf(fminf(fx, fy), fz);
-        const bool hit = ((uint32_t)k < nchild) && (lo <= hi) && (hi >= 0.0f) && (lo <= limit);
+        // bitwise: all four children are tested without branches
+        const bool hit = ((uint32_t)k < nchild) & (lo <= hi) & (hi >= 0.0f) & (lo <= limit);
         t[k] = hit ? lo : inf;
     }
 }
@@ -206,6 +207,8 @@ RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const Ra
 // becomes the next node and the others are pushed, farthest first.
 // Returns the next reference, or `done` when nothing is hit and the stack is empty.
 // The lane's stack holds entries [bot, sp): bot > 0 once the oldest entries were given away (rtx_coop.h).
+// SORT = false (any-hit queries): the order of the children does not matter, they are taken as stored.
+template <bool SORT = true>
 RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D, const RayBox& rb, V3 o, float limit,
                      TravStack& st, int& sp, int bot, int done) {
 #ifdef RTX_COUNT_STEPS
@@ -234,9 +237,9 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
             const unsigned short hs = (unsigned short)hbits;
             _Float16 hf;
             __builtin_memcpy(&hf, &hs, 2);
-            const float rq = (float)hf;
+            const float rq = fminf((float)hf, 65504.0f);             // +inf (no sphere) -> finite, masked below
             const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
-            e[k] = (hbits == 0x7c00u) ? 0.0f : kd2 * __builtin_amdgcn_rcpf(den) * 1.002f;
+            e[k] = kd2 * __builtin_amdgcn_rcpf(den) * ((hbits != 0x7c00u) ? 1.002f : 0.0f);
         }
         node4_slabs<true>(B, C, nchild, rb, limit, sx, sy, sz, lx, ly, lz, hx, hy, hz, e, t);
     } else {
@@ -249,12 +252,24 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
         const int ra = sw ? r[j] : r[i], rb_ = sw ? r[i] : r[j];  \
         t[i] = ta; t[j] = tb; r[i] = ra; r[j] = rb_;   \
     } while (0)
-    RTX_CE(0, 1); RTX_CE(2, 3); RTX_CE(0, 2); RTX_CE(1, 3); RTX_CE(1, 2);
+    if (SORT) {
+        RTX_CE(0, 1); RTX_CE(2, 3); RTX_CE(0, 2); RTX_CE(1, 3); RTX_CE(1, 2);
+        if (t[3] < inf) st.put(sp++, r[3]);
+        if (t[2] < inf) st.put(sp++, r[2]);
+        if (t[1] < inf) st.put(sp++, r[1]);
+        if (t[0] < inf) return r[0];
+    } else {
+        int next = done;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            if (t[k] < inf) {
+                if (next != done) st.put(sp++, next);
+                next = r[k];
+            }
+        }
+        if (next != done) return next;
+    }
 #undef RTX_CE
-    if (t[3] < inf) st.put(sp++, r[3]);
-    if (t[2] < inf) st.put(sp++, r[2]);
-    if (t[1] < inf) st.put(sp++, r[1]);
-    if (t[0] < inf) return r[0];
     if (sp == bot) return done;
     return st.get(--sp);
 }
@@ -349,7 +364,7 @@ RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack&
     while (cur != kRefDone) {
         const Fetched f = fetch_ref(s, cur);
         if (cur >= 0) {
-            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, 0, kRefDone);
+            cur = node4_step<false>(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, 0, kRefDone);
         } else {
             const uint32_t leaf = ~(uint32_t)cur;
             const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;

@@ -108,6 +108,35 @@ def test_frame_is_reproducible_and_shardable(big, rtx):
     assert np.array_equal(img.cpu().numpy().reshape(h, w, 3), a)
 
 
+@pytest.mark.parametrize("kind", ["reflective_glass", "tiny_spheres"])
+def test_cooperative_traversal_is_exact(kind, rtx, synth):
+    """The wavefront-cooperative phase (idle lanes take subtrees of busy lanes) must not change
+    any result: never cooperative (tune0 = 0) against cooperative from the first step (tune0 = 64),
+    for closest-hit ids / t, for frames with any-hit shadows and for closest-hit shadows through glass."""
+    flat = synth.heightfield_scene(128, spec=0.3, glass_lattice=8) if kind == "reflective_glass" else \
+        synth.heightfield_scene(128, spec=0.0, small_spheres=20000)
+    rng = np.random.default_rng(3)
+    n = 40000
+    tri = flat.tri_pos[rng.integers(0, flat.n_tris, n)]
+    ori = tri.mean(axis=1).astype(np.float32)
+    ori[:, 1] += np.float32(2e-4)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = np.abs(d[:, 1]) * 0.02          # grazing rays: long traversals, few hits
+    out = {}
+    for thr in (0, 64):
+        with rtx.Context(0) as ctx:
+            ctx.set_option("tune0", thr)
+            ctx.set_scene(flat)
+            ctx.build()
+            out[thr] = (ctx.intersect_batch(ori, d), ctx.primary_hits(320, 180), ctx.render(320, 180, 5, 10))
+    (pa, ta), (ha, hta, _), (ra, sa) = out[0]
+    (pb, tb), (hb, htb, _), (rb, sb) = out[64]
+    assert np.array_equal(pa, pb) and np.array_equal(_bits(ta)[pa >= 0], _bits(tb)[pa >= 0])
+    assert np.array_equal(ha, hb) and np.array_equal(_bits(hta)[ha >= 0], _bits(htb)[ha >= 0])
+    assert np.array_equal(ra, rb)
+    assert sa.traced_rays == sb.traced_rays and sa.shadow_rays == sb.shadow_rays
+
+
 def test_render_device_writes_the_same_row_major_frame(big):
     """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
     import torch
