@@ -53,14 +53,17 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--spec", type=float, default=0.0)
     ap.add_argument("--glass", type=int, default=0)
-    ap.add_argument("--cpu-stride", type=int, default=128)
+    ap.add_argument("--cpu-stride", type=int, default=28, help="CPU baseline samples every n-th pixel in x and y (28: about 15 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="traversal kernel variant (rtx_set_option trace_variant)")
     ap.add_argument("--tune", type=str, default="", help="comma-separated tune0..3 overrides (experiments)")
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
                          "collectives through host memory, ranks may share a GPU)")
+    ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
+    if args.lib:
+        os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", args.lib)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

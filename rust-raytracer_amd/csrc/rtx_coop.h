@@ -103,9 +103,11 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
     }
 
     // ---- phase 2: idle lanes take subtrees from busy lanes ----
-    volatile unsigned long long* slot = L.slot + (threadIdx.x & ~63u);   // this wavefront's 64 slots
-    volatile int* pair = L.pair + (threadIdx.x & ~63u);
-    slot[lane] = ANY ? (best_id ? 0ull : 1ull) : (((unsigned long long)f2u(best_t) << 32) | (uint32_t)best_id);
+    RTX_LDS_PTR(unsigned long long) slot = (RTX_LDS_PTR(unsigned long long))L.slot + (threadIdx.x & ~63u);   // this wavefront's 64 slots
+    RTX_LDS_PTR(int) pair = (RTX_LDS_PTR(int))L.pair + (threadIdx.x & ~63u);
+    // LDS operations of one wavefront execute in order; wavefront-scope atomics keep the compiler from caching them
+    __hip_atomic_store(&slot[lane], ANY ? (best_id ? 0ull : 1ull) : (((unsigned long long)f2u(best_t) << 32) | (uint32_t)best_id),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     int owner = lane, bot = 0;
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (;;) {
@@ -118,9 +120,9 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             const int np = min(__popcll(~busy), __popcll(don));
             const int rd = __popcll(don & lt), ri = __popcll(~busy & lt);
             const bool giver = can_give && rd < np, taker = !has && ri < np;
-            if (giver) pair[rd] = lane;
+            if (giver) __hip_atomic_store(&pair[rd], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             __builtin_amdgcn_wave_barrier();
-            const int src = taker ? pair[ri] : lane;
+            const int src = taker ? __hip_atomic_load(&pair[ri], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : lane;
             __builtin_amdgcn_wave_barrier();
             const int bref = can_give ? st.get(bot) : 0;
             const int t_ref = __shfl(bref, src), t_owner = __shfl(owner, src);
@@ -147,7 +149,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             }
         }
         if (cur != kRefDone) {
-            const unsigned long long key = slot[owner];
+            const unsigned long long key = __hip_atomic_load(&slot[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (ANY && key == 0ull) {   // another lane found an occluder for this ray
                 cur = kRefDone;
                 sp = bot;
@@ -162,7 +164,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                         bool occ = any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
                         for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record(s.recs, first + k, o, d, dist_light);
                         if (occ) {
-                            slot[owner] = 0ull;
+                            __hip_atomic_store(&slot[owner], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             sp = bot;
                         }
                     } else {
@@ -173,8 +175,8 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                         test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, bt, bi);
                         for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, bt, bi);
                         if (bt != bt0 || bi != bi0)
-                            atomicMin((unsigned long long*)&L.slot[(threadIdx.x & ~63u) + owner],
-                                      ((unsigned long long)f2u(bt) << 32) | (uint32_t)bi);
+                            __hip_atomic_fetch_min(&slot[owner], ((unsigned long long)f2u(bt) << 32) | (uint32_t)bi, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
 #ifdef RTX_COUNT_STEPS
                     st.leaves += cnt;
@@ -184,7 +186,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             }
         }
     }
-    const unsigned long long key = slot[lane];
+    const unsigned long long key = __hip_atomic_load(&slot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (ANY) {
         out_t = 0.0f;
         out_id = (key == 0ull) ? 1 : 0;

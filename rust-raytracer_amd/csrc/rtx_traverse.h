@@ -135,8 +135,12 @@ RTX_D bool in_safe_region(const DevScene& s, V3 o) {
 // what lets 8 workgroups (32 wavefronts) share a CU. The spill area has
 // DevScene::spill_stride thread slots, so traversal grids are bounded by it.
 #define RTX_STACK_LDS 16
+// Pointers into LDS carry their address space, so stack accesses compile to ds_read / ds_write
+// (a generic pointer would turn them into flat accesses that also count as vector-memory
+// operations and force the traversal to wait for its node fetch before touching the stack).
+#define RTX_LDS_PTR(T) __attribute__((address_space(3))) T*
 struct TravStack {
-    int* base;
+    RTX_LDS_PTR(int) base;
     int* spill;
     uint32_t spill_stride;
 #ifdef RTX_COUNT_STEPS
@@ -144,7 +148,7 @@ struct TravStack {
     uint32_t leaves = 0;  // diagnostic build: primitive tests of this lane
 #endif
     RTX_D void set(int* lds, const DevScene& s) {
-        base = lds + threadIdx.x;
+        base = (RTX_LDS_PTR(int))lds + threadIdx.x;
         spill = s.spill + (blockIdx.x * RTX_BLOCK + threadIdx.x);
         spill_stride = s.spill_stride;
     }
