@@ -70,8 +70,16 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
     for (;;) {
         busy = __ballot(cur != kRefDone);
         if (busy == 0 || __popcll(busy) < threshold) break;
+#ifdef RTX_COUNT_STEPS
+        const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
         if (cur != kRefDone) {
             const Fetched f = fetch_ref(s, cur);
+#ifdef RTX_COUNT_STEPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long c1 = __builtin_readcyclecounter();
+            st.t_mem += c1 - c0;
+#endif
             if (cur >= 0) {
                 cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
             } else {
@@ -93,6 +101,9 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
 #endif
                 cur = (sp == 0) ? kRefDone : st.get(--sp);
             }
+#ifdef RTX_COUNT_STEPS
+            st.t_alu += __builtin_readcyclecounter() - c1;
+#endif
         }
     }
 #endif
@@ -111,6 +122,9 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
     int owner = lane, bot = 0;
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (;;) {
+#ifdef RTX_COUNT_STEPS
+        const unsigned long long d0 = __builtin_readcyclecounter();
+#endif
         const bool has = cur != kRefDone;
         busy = __ballot(has);
         if (busy == 0) break;
@@ -148,6 +162,10 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                 sp = bot = 0;
             }
         }
+#ifdef RTX_COUNT_STEPS
+        const unsigned long long d1 = __builtin_readcyclecounter();
+        st.t_don += d1 - d0;
+#endif
         if (cur != kRefDone) {
             const unsigned long long key = __hip_atomic_load(&slot[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (ANY && key == 0ull) {   // another lane found an occluder for this ray
@@ -155,6 +173,11 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                 sp = bot;
             } else {
                 const Fetched f = fetch_ref(s, cur);
+#ifdef RTX_COUNT_STEPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long d2 = __builtin_readcyclecounter();
+                st.t_mem += d2 - d1;
+#endif
                 if (cur >= 0) {
                     cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
                 } else {
@@ -183,6 +206,9 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
 #endif
                     cur = (sp == bot) ? kRefDone : st.get(--sp);
                 }
+#ifdef RTX_COUNT_STEPS
+                st.t_alu += __builtin_readcyclecounter() - d2;
+#endif
             }
         }
     }

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         }
 #endif
     }
+#ifdef RTX_COUNT_STEPS
+    ws.prof = ((st.t_mem >> 8) & 0x1fffff) | (((st.t_alu >> 8) & 0x1fffff) << 21) | (((st.t_don >> 8) & 0x1fffff) << 42);
+#endif
     ws.end();
 }
 
@@ -555,6 +558,9 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
             }
         }
     }
+#ifdef RTX_COUNT_STEPS
+    ws.prof = ((st.t_mem >> 8) & 0x1fffff) | (((st.t_alu >> 8) & 0x1fffff) << 21) | (((st.t_don >> 8) & 0x1fffff) << 42);
+#endif
     ws.end();
     unsigned long long rays = task.rays;
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);

@@ -92,6 +92,7 @@ struct WaveStamp {
     unsigned long long* rec;
     unsigned long long units;
     unsigned long long step_sum = 0, step_max = 0;   // diagnostic build (RTX_COUNT_STEPS) only
+    unsigned long long prof = 0;                      // diagnostic build: (t_mem, t_alu, t_don) >> 8 in 21 bits each
     // Adds one unit's per-lane step counts: sum over lanes and the slowest lane.
     RTX_D void add_steps(uint32_t lane_steps) {
         uint32_t sum = lane_steps, mx = lane_steps;
@@ -118,6 +119,9 @@ struct WaveStamp {
             rec[1] = wall_clock64();
             rec[2] = units | (step_max << 16) | (step_sum << 40);
             rec[3] = (xcc & 0xfu) | (((hw >> 13) & 0x7u) << 8) | (((hw >> 8) & 0xfu) << 16);
+#ifdef RTX_COUNT_STEPS
+            rec[3] = prof;   // diagnostic build: cycle split instead of the placement
+#endif
         }
     }
 };
@@ -146,6 +150,7 @@ struct TravStack {
 #ifdef RTX_COUNT_STEPS
     uint32_t steps = 0;   // diagnostic build: node steps of this lane
     uint32_t leaves = 0;  // diagnostic build: primitive tests of this lane
+    unsigned long long t_mem = 0, t_alu = 0, t_don = 0;   // diagnostic build: shader cycles waiting for the fetch / computing / giving work
 #endif
     RTX_D void set(int* lds, const DevScene& s) {
         base = (RTX_LDS_PTR(int))lds + threadIdx.x;

@@ -31,6 +31,22 @@ def summarize(name, rec):
     se = ((rec[:, 3] >> 8) & 0xff).astype(np.int64)
     cu = ((rec[:, 3] >> 16) & 0xff).astype(np.int64)
     span = end.max()
+    prof = None
+    if step_sum.sum() or (rec[:, 3] >> 21).any():   # diagnostic build: rec[3] holds the cycle split (units of 256 shader cycles)
+        t_mem = (rec[:, 3] & 0x1fffff).astype(np.float64) * 256
+        t_alu = ((rec[:, 3] >> 21) & 0x1fffff).astype(np.float64) * 256
+        t_don = ((rec[:, 3] >> 42) & 0x1fffff).astype(np.float64) * 256
+        life = (end - start) * 1e-6                          # seconds
+        tot = t_mem + t_alu + t_don
+        ghz = tot.sum() / life.sum() / 1e9                   # lower bound of the shader clock: cycles accounted per second of life
+        last = np.argsort(end)[-64:]
+        prof = {"mem_wait_share": float(t_mem.sum() / tot.sum()), "compute_share": float(t_alu.sum() / tot.sum()),
+                "donation_share": float(t_don.sum() / tot.sum()), "accounted_gcycles_per_s": float(ghz),
+                "last64_waves": {"mem_wait_share": float(t_mem[last].sum() / tot[last].sum()),
+                                 "compute_share": float(t_alu[last].sum() / tot[last].sum()),
+                                 "donation_share": float(t_don[last].sum() / tot[last].sum()),
+                                 "accounted_gcycles_per_s": float(tot[last].sum() / life[last].sum() / 1e9)}}
+        xcc = xcc * 0
     q = lambda a: [float(np.percentile(a, p)) for p in (0, 10, 50, 90, 100)]
     per_xcc = {int(x): {"waves": int((xcc == x).sum()), "units": int(units[xcc == x].sum()),
                         "last_end_us": float(end[xcc == x].max())} for x in np.unique(xcc)}
@@ -39,7 +55,7 @@ def summarize(name, rec):
             "start_us_p0_10_50_90_100": q(start), "end_us_p0_10_50_90_100": q(end),
             "resident_fraction": float((end - start).sum() / (span * len(rec))),
             "units_total": int(units.sum()), "units_per_wave_p0_10_50_90_100": q(units),
-            "idle_waves": int((units == 0).sum()),
+            "idle_waves": int((units == 0).sum()), "cycle_split": prof,
             "steps": None if step_sum.sum() == 0 else {
                 "lane_steps_total": int(step_sum.sum()), "wave_steps_total": int(step_max.sum()),
                 "lane_utilisation": float(step_sum.sum() / (64.0 * step_max.sum())),
