@@ -297,11 +297,26 @@ struct Fetched {
 RTX_D Fetched fetch_ref(const DevScene& s, int cur) {
     const uint4* p = (cur >= 0) ? reinterpret_cast<const uint4*>(s.nodes + cur)
                                 : reinterpret_cast<const uint4*>(s.recs + (~(uint32_t)cur >> 3));
+    // Four 16-byte loads issued back to back and one wait, spelled out: left to itself the
+    // compiler splits the 64 bytes by field use and sinks the parts only the node path reads
+    // behind the branch, which adds load instructions (each costs the CU's address unit one
+    // access per lane) and a second memory wait to every node step.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 a, b, c, d;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:16\n\t"
+        "global_load_dwordx4 %2, %4, off offset:32\n\t"
+        "global_load_dwordx4 %3, %4, off offset:48\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(p)
+        : "memory");
     Fetched f;
-    f.a = p[0];
-    f.b = p[1];
-    f.c = p[2];
-    f.d = p[3];
+    f.a = make_uint4(a.x, a.y, a.z, a.w);
+    f.b = make_uint4(b.x, b.y, b.z, b.w);
+    f.c = make_uint4(c.x, c.y, c.z, c.w);
+    f.d = make_uint4(d.x, d.y, d.z, d.w);
     return f;
 }
 RTX_D float4 as_f4(uint4 u) { return make_float4(u2f(u.x), u2f(u.y), u2f(u.z), u2f(u.w)); }
