@@ -92,6 +92,8 @@ void rtx_destroy(rtx_context* ctx) {
     free_list(ctx->scene_allocs);
     free_list(ctx->build_allocs);
     free_list(ctx->work_allocs);
+    for (auto& e : ctx->order_bufs) (void)hipFree(e.second);
+    ctx->order_bufs.clear();
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -125,6 +127,8 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
+    } else if (k == "cost_order") {
+        ctx->opt_cost_order = value ? 1 : 0;
     } else if (k == "stamps") {
         ctx->opt_stamps = value ? 1 : 0;
         ctx->built = false;   // the stamp buffer is allocated by rtx_build
@@ -171,6 +175,8 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
 
     free_list(ctx->scene_allocs);
     free_list(ctx->build_allocs);
+    for (auto& e : ctx->order_bufs) (void)hipFree(e.second);   // unit costs of the previous scene
+    ctx->order_bufs.clear();
     ctx->has_scene = false;
     ctx->built = false;
     const auto t0 = std::chrono::steady_clock::now();

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtx.h"
@@ -138,6 +139,8 @@ struct rtx_context {
     uint32_t num_cus = 256;
     int32_t opt_tune[4] = {48, 8, 4, RTX_LEAF_MAX};
     int64_t opt_stamps = 0;
+    int64_t opt_cost_order = 1;   // level-0 traversal launches hand out their units most expensive first (costs of the previous frame)
+    std::vector<std::pair<uint64_t, void*>> order_bufs;   // (kind, batch, capacity) -> UnitOrder
 };
 
 // -- helpers shared by the translation units ---------------------------------

@@ -176,15 +176,49 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(PrimaryGen pg, Work wk, ui
 // workgroup starts on shard blockIdx % 8 -- workgroups b and b+8 usually share an XCD, so
 // a shard's rays stay in one L2 -- and moves on to the other shards when it runs dry.
 // One word would serve only ~90 atomics per microsecond; eight shards do not limit a launch.
+// Cost-ordered units. A launch ends with its slowest units, and those are slow because
+// their rays are (a few rays grazing the surface take ten times the steps of the rest), so
+// the launch is shortest when the expensive units start first. What a unit costs is not
+// known before it ran, but the previous frame knows: every unit records its duration, a
+// small kernel (k_order_units, off the critical path) sorts the units by it, and the next
+// launch of the same kind hands units out in that order whenever its unit count equals the
+// recorded one -- a re-render, the next sample of the same view, or the next frame of a
+// slowly moving camera. Any permutation of the units gives the same image; with no valid
+// order the units go out in index order.
+// Costs are kept per GROUP of 8 consecutive units (neighbouring tiles cost about the same):
+// sorting a frame's few thousand groups takes one small workgroup a few microseconds, and a
+// group stays together on one shard, which keeps its nodes in one XCD's L2.
+constexpr uint32_t kGroupLog2 = 3, kGroup = 1u << kGroupLog2;
+struct UnitOrder {
+    uint32_t n_cost;    // unit count of the launch that last added to cost[] (0: none, or too many for cap)
+    uint32_t n_order;   // unit count whose groups order[] is a permutation of (0: none)
+    uint32_t cap, pad;  // capacity in groups
+    RTX_D uint32_t* cost() { return reinterpret_cast<uint32_t*>(this + 1); }          // [cap] summed durations, 10 ns ticks
+    RTX_D uint32_t* order() { return reinterpret_cast<uint32_t*>(this + 1) + cap; }   // [cap] groups, most expensive first
+};
+
 struct UnitQueue {
     uint32_t* heads;        // [8][32]
-    uint32_t n_units, per_shard, shard, probe;
-    RTX_D void init(uint32_t* h, uint64_t n_items) {
+    uint32_t n_units, n_groups, per_shard, shard, probe;
+    const uint32_t* order;  // sorted position -> group, or nullptr
+    UnitOrder* uo;
+    RTX_D void init(uint32_t* h, uint64_t n_items, UnitOrder* uo_) {
         heads = h;
         n_units = (uint32_t)((n_items + 63) >> 6);
+        n_groups = (n_units + kGroup - 1) >> kGroupLog2;
         per_shard = (n_units + 7) >> 3;
         shard = blockIdx.x & 7u;
         probe = 0;
+        uo = uo_;
+        order = (uo && n_units > 0 && uo->n_order == n_units) ? uo->order() : nullptr;
+    }
+    // Called once per launch by every wavefront after init (only one thread writes).
+    RTX_D void announce() {
+        if (uo && blockIdx.x == 0 && threadIdx.x == 0) uo->n_cost = (n_groups <= uo->cap) ? n_units : 0u;
+    }
+    RTX_D void record(uint32_t unit, unsigned long long t0) {
+        if (uo && (threadIdx.x & 63) == 0 && (unit >> kGroupLog2) < uo->cap)
+            atomicAdd(&uo->cost()[unit >> kGroupLog2], (uint32_t)(wall_clock64() - t0));
     }
     // Wave-uniform: next unit for this wavefront, or 0xffffffff when every shard is empty.
     RTX_D uint32_t next() {
@@ -192,10 +226,20 @@ struct UnitQueue {
         if ((threadIdx.x & 63) == 0) {
             while (probe < 8) {
                 const uint32_t sh = (shard + probe) & 7u;
-                const uint32_t lo = sh * per_shard, hi = min(lo + per_shard, n_units);
-                if (lo < hi) {
-                    const uint32_t u = lo + atomicAdd(&heads[sh * 32], 1u);
-                    if (u < hi) { unit = u; break; }
+                if (order) {   // shard sh owns the groups at sorted positions sh, sh + 8, ...: every shard starts with expensive ones
+                    const uint32_t k = atomicAdd(&heads[sh * 32], 1u);
+                    const uint32_t gpos = (k >> kGroupLog2) * 8u + sh;
+                    if (gpos < n_groups) {
+                        const uint32_t u = order[gpos] * kGroup + (k & (kGroup - 1u));
+                        if (u < n_units) { unit = u; break; }
+                        continue;   // past the end of the last, partial group
+                    }
+                } else {
+                    const uint32_t lo = sh * per_shard, hi = min(lo + per_shard, n_units);
+                    if (lo < hi) {
+                        const uint32_t u = lo + atomicAdd(&heads[sh * 32], 1u);
+                        if (u < hi) { unit = u; break; }
+                    }
                 }
                 ++probe;
             }
@@ -204,9 +248,71 @@ struct UnitQueue {
     }
 };
 
+// Sorts the groups of the last launch by recorded cost, most expensive first, and clears the
+// costs for the next recording: a stable counting sort into 16 classes (two per octave below
+// the largest cost), so groups of similar cost keep their index order. One workgroup.
+constexpr int kOrderThreads = 512, kOrderClasses = 16;
+__global__ __launch_bounds__(kOrderThreads) void k_order_units(UnitOrder* uo) {
+    __shared__ uint32_t offs[kOrderClasses * kOrderThreads];   // [class][thread]: count, then start position
+    __shared__ uint32_t wave_sum[kOrderThreads / 64];
+    __shared__ uint32_t s_max;
+    const uint32_t n_units = uo->n_cost;
+    const uint32_t n = (n_units + kGroup - 1) >> kGroupLog2;
+    const uint32_t t = threadIdx.x;
+    if (n_units == 0 || n > uo->cap) {   // block-uniform
+        if (t == 0) uo->n_order = 0;
+        return;
+    }
+    uint32_t* cost = uo->cost();
+    uint32_t* order = uo->order();
+    const uint32_t per = (n + kOrderThreads - 1) / kOrderThreads;
+    const uint32_t lo = min(t * per, n), hi = min(lo + per, n);   // thread t sorts the groups [lo, hi)
+    if (t == 0) s_max = 1;
+    for (int k = 0; k < kOrderClasses; ++k) offs[k * kOrderThreads + t] = 0;
+    __syncthreads();
+    uint32_t mx = 1;
+    for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost[u]);
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const int top = 2 * (31 - __clz((int)s_max)) + 1;
+    auto cls = [top](uint32_t c) {   // 0 = the half octave of the largest cost
+        c = max(c, 1u);
+        const int e = 31 - __clz((int)c);
+        const int half = (e > 0) ? (int)((c >> (e - 1)) & 1u) : 0;
+        return min(kOrderClasses - 1, top - (2 * e + half));
+    };
+    for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost[u]) * kOrderThreads + t];
+    __syncthreads();
+    // Exclusive scan of the class-major, thread-minor sequence in place; thread t scans the
+    // 16 consecutive entries [16 t, 16 t + 16).
+    uint32_t sum = 0;
+    for (int k = 0; k < kOrderClasses; ++k) {
+        const uint32_t c = offs[t * kOrderClasses + k];
+        offs[t * kOrderClasses + k] = sum;
+        sum += c;
+    }
+    uint32_t incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((int)(t & 63) >= o) incl += v;
+    }
+    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (uint32_t w = 0; w < (t >> 6); ++w) base += wave_sum[w];
+    for (int k = 0; k < kOrderClasses; ++k) offs[t * kOrderClasses + k] += base;
+    __syncthreads();
+    for (uint32_t u = lo; u < hi; ++u) {
+        order[offs[cls(cost[u]) * kOrderThreads + t]++] = u;
+        cost[u] = 0;
+    }
+    __syncthreads();
+    if (t == 0) uo->n_order = n_units;
+}
+
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
     TravStack st;
@@ -216,8 +322,10 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
     WaveStamp ws;
     ws.begin(s, 0);
     UnitQueue uq;
-    uq.init(&ctl->unit_head[0][0][0], n);
+    uq.init(&ctl->unit_head[0][0][0], n, uo);
+    uq.announce();
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        const unsigned long long unit_start = wall_clock64();
         ++ws.units;
         const uint32_t i = unit * 64 + (threadIdx.x & 63);
 #ifdef RTX_COUNT_STEPS
@@ -239,6 +347,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         coop_trace<false>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
+        uq.record(unit, unit_start);
 #ifdef RTX_COUNT_STEPS
         ws.add_steps(st.steps);
         if (s.stamps) {   // per-unit record after the two wave tables: (start, duration | max iterations << 24 | sum << 44)
@@ -521,7 +630,7 @@ struct ShadowTask {
 };
 
 template <bool ANY, bool AREA>
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
     TravStack st;
@@ -540,8 +649,10 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
     WaveStamp ws;
     ws.begin(s, 1);
     UnitQueue uq;
-    uq.init(&ctl->unit_head[1][0][0], total);
+    uq.init(&ctl->unit_head[1][0][0], total, uo);
+    uq.announce();
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+        const unsigned long long unit_start = wall_clock64();
         ++ws.units;
         const uint64_t k = (uint64_t)unit * 64 + (threadIdx.x & 63);
         V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
@@ -557,6 +668,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
                 if (live) live = task.finish_closest(id, t, o, d);
             }
         }
+        uq.record(unit, unit_start);
     }
 #ifdef RTX_COUNT_STEPS
     ws.prof = ((st.t_mem >> 8) & 0x1fffff) | (((st.t_alu >> 8) & 0x1fffff) << 21) | (((st.t_don >> 8) & 0x1fffff) << 42);
@@ -874,10 +986,12 @@ PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
     const uint32_t blocks = trav_blocks(ctx, ((chunks + 3) / 4) * RTX_BLOCK);
     return PersistGrid{blocks, blocks * 4 * kChunk};
 }
-void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, hipStream_t st) {
+void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
+                    hipStream_t st) {
     const DevScene& s = ctx->ds;
     if (ctx->opt_trace_variant == 0) {
-        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg);
+        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg, uo);
+        if (uo) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(kOrderThreads), 0, st, uo);
     } else {
         if (pg.enabled)   // the persistent variant reads its rays from the queue
             hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_upper, 1u << 22)), dim3(RTX_BLOCK), 0, st, pg, wk, n_upper);
@@ -886,20 +1000,42 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
     }
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
-                   hipStream_t st) {
+                   UnitOrder* uo, hipStream_t st) {
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
     if (ctx->opt_trace_variant == 0 || area) {   // the persistent variant has no sample slots
         const dim3 grid(trav_blocks(ctx, tasks_upper)), block(RTX_BLOCK);
-        if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots);
-        else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots);
-        else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots);
-        else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots);
+        if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+        else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+        else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+        else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+        if (uo) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(kOrderThreads), 0, st, uo);
     } else {
         const PersistGrid g = persist_grid(ctx, tasks_upper);
         if (any) hipLaunchKernelGGL(k_shadow_p<true>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
         else hipLaunchKernelGGL(k_shadow_p<false>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
     }
+}
+
+// The cost / order buffer of one (kind, batch) pair of level-0 launches; nullptr when the
+// option is off or the allocation fails (the launch then uses index order).
+UnitOrder* unit_order(rtx_context* ctx, uint32_t kind, uint32_t batch_index, uint64_t cap_groups) {
+    if (!ctx->opt_cost_order || batch_index >= 64 || cap_groups == 0 || cap_groups > (1u << 26)) return nullptr;
+    const uint64_t cap_units = cap_groups;   // array length
+    const uint64_t key = ((uint64_t)kind << 40) | ((uint64_t)batch_index << 32) | cap_groups;
+    for (auto& e : ctx->order_bufs)
+        if (e.first == key) return (UnitOrder*)e.second;
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(UnitOrder) + 2 * cap_units * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    UnitOrder hdr{0u, 0u, (uint32_t)cap_units, 0u};
+    if (hipMemsetAsync(p, 0, sizeof(UnitOrder) + 2 * cap_units * sizeof(uint32_t), ctx->stream) != hipSuccess ||   // costs are sums
+        hipMemcpyAsync(p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
+    ctx->order_bufs.emplace_back(key, p);
+    return (UnitOrder*)p;
 }
 
 }  // namespace
@@ -986,13 +1122,15 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         int qi = 0;
         uint32_t n_rays = n, levels_done = 0;
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
-            launch_closest(ctx, wk, 0, n_rays, gen, st);
+            launch_closest(ctx, wk, 0, n_rays, gen, nullptr, st);
         for (uint32_t level = 0; level < levels; ++level) {
             hipEvent_t a = ev.next(), b = ev.next();
             if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
             RTX_HIP(ctx, hipEventRecord(a, st));
             const PrimaryGen& pg = (level == 0) ? gen : no_gen;
-            launch_closest(ctx, wk, qi, n_rays, pg, st);
+            // level-0 launches of unchanged size reuse the unit costs of the previous frame (see UnitOrder)
+            const bool ordered = level == 0 && cur_batch == batch;
+            launch_closest(ctx, wk, qi, n_rays, pg, ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
@@ -1002,7 +1140,8 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
                 RTX_HIP(ctx, hipEventRecord(c, st));
                 const uint64_t tasks = (uint64_t)n_rays * n_slots;
-                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, st);
+                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow,
+                              ordered ? unit_order(ctx, 1, n_batches - 1, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup) : nullptr, st);
                 RTX_HIP(ctx, hipEventRecord(d, st));
                 shadow_events.emplace_back(c, d);
             }
@@ -1096,7 +1235,7 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
         hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0, 1);
         const PrimaryGen gen{cam, first, 0u, 1u, tiles_x, (uint32_t)n_tiles, 1u};
         hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, gen, wk, n);   // k_primary_out reads the directions
-        launch_closest(ctx, wk, 0, n, gen, st);
+        launch_closest(ctx, wk, 0, n, gen, nullptr, st);
         hipLaunchKernelGGL(k_primary_out, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, wk.q[0], first, n, w, h, tiles_x,
                            d_prim, d_t, d_dir);
     }

@@ -171,7 +171,10 @@ RTX_D Col direct_lightning(const DevLight& l, V3 point, V3 normal, V3 ray_dir, C
         V3 rj = vmult(vmult(normal, t), 2.0f);
         rj = rj - dir;
         t = fmaxf(vdot(rj, v), 0.0f);
-        const Col specular_light = col_mult(ks, powf(t, q));
+        // ks == 0 and a base in [0, 1] with a non-negative exponent: powf is finite, so ks * powf is
+        // exactly zero and the call (the most expensive operation of the shading pass) can be skipped
+        const bool matte = ks.r == 0.0f && ks.g == 0.0f && ks.b == 0.0f && t <= 1.0f && q >= 0.0f;
+        const Col specular_light = matte ? col_new() : col_mult(ks, powf(t, q));
         Col sample = direct_light * (diffuse_light + specular_light);
         sample = col_init(sample.r / nf, sample.g / nf, sample.b / nf);
         lightning = lightning + sample;
