@@ -48,6 +48,9 @@ struct Work {
     float4 *pL, *pC0, *pC1;      // retained pool: (local colour, mat0), reflected child colour, refracted child colour
     uint32_t* pLink;             // retained pool: parent link
     uint64_t* pKey;              // retained pool: sampling key of the node; nullptr without area lights
+    // Hits per chunk of 2048 rays (counted by the closest-hit kernel) and their exclusive prefix
+    // (k_scan_chunks): node slots follow ray order, whatever order the workgroups run in.
+    uint32_t *chunk_cnt, *chunk_base;
     uint32_t cap_pool;
     uint32_t n_samples;          // RayTracer::num_samples, at least 1 here
     uint32_t area_off;           // num_samples == 0: area lights trace nothing and contribute nothing
@@ -250,9 +253,11 @@ struct UnitQueue {
 
 // Sorts the groups of the last launch by recorded cost, most expensive first, and clears the
 // costs for the next recording: a stable counting sort into 16 classes (two per octave below
-// the largest cost), so groups of similar cost keep their index order. One workgroup.
-constexpr int kOrderThreads = 512, kOrderClasses = 16;
-__global__ __launch_bounds__(kOrderThreads) void k_order_units(UnitOrder* uo) {
+// the largest cost), so groups of similar cost keep their index order. Work for ONE workgroup
+// of 256 threads; the shading kernel that follows a traversal launch gives it to one of its
+// workgroups, which costs no launch and hides behind the other workgroups.
+constexpr int kOrderThreads = RTX_BLOCK, kOrderClasses = 16;
+RTX_D void order_units(UnitOrder* uo) {
     __shared__ uint32_t offs[kOrderClasses * kOrderThreads];   // [class][thread]: count, then start position
     __shared__ uint32_t wave_sum[kOrderThreads / 64];
     __shared__ uint32_t s_max;
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_units(UnitOrder* uo) {
     const uint32_t t = threadIdx.x;
     if (n_units == 0 || n > uo->cap) {   // block-uniform
         if (t == 0) uo->n_order = 0;
+        __syncthreads();
         return;
     }
     uint32_t* cost = uo->cost();
@@ -308,11 +314,12 @@ __global__ __launch_bounds__(kOrderThreads) void k_order_units(UnitOrder* uo) {
     }
     __syncthreads();
     if (t == 0) uo->n_order = n_units;
+    __syncthreads();
 }
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
     TravStack st;
@@ -347,6 +354,8 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         coop_trace<false>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
+        const uint64_t hits = __ballot(i < n && id >= 0);
+        if (chunk_cnt && hits && (threadIdx.x & 63) == 0) atomicAdd(&chunk_cnt[unit >> 5], (uint32_t)__popcll(hits));   // 32 units = one chunk of k_shade_a
         uq.record(unit, unit_start);
 #ifdef RTX_COUNT_STEPS
         ws.add_steps(st.steps);
@@ -407,12 +416,41 @@ RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as
 // slots with ONE atomic, so the node order follows the ray order inside a chunk and
 // the global counter sees ~n/2048 atomics instead of one per wavefront.
 constexpr int kShadeItems = 8;
+static_assert(RTX_BLOCK * kShadeItems == 64 * 32, "a chunk of k_shade_a is 32 units of the closest-hit kernel");
+
+// Exclusive prefix of the per-chunk hit counts (one workgroup; at most a few thousand chunks);
+// sets the level's node count and clears the counts for the next launch.
+__global__ __launch_bounds__(RTX_BLOCK) void k_scan_chunks(Ctl* ctl, int qi, uint32_t* __restrict__ cnt, uint32_t* __restrict__ base) {
+    __shared__ uint32_t wave_sum[RTX_BLOCK / 64];
+    const uint32_t n_chunks = (ctl->n_rays[qi] + RTX_BLOCK * kShadeItems - 1) / (RTX_BLOCK * kShadeItems);
+    const uint32_t per = (n_chunks + RTX_BLOCK - 1) / RTX_BLOCK;
+    const uint32_t t = threadIdx.x, lo = min(t * per, n_chunks), hi = min(lo + per, n_chunks);
+    uint32_t sum = 0;
+    for (uint32_t c = lo; c < hi; ++c) sum += cnt[c];
+    uint32_t incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((int)(t & 63) >= o) incl += v;
+    }
+    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (t >> 6); ++w) run += wave_sum[w];
+    for (uint32_t c = lo; c < hi; ++c) {
+        base[c] = run;
+        run += cnt[c];
+        cnt[c] = 0;
+    }
+    if (t == RTX_BLOCK - 1) ctl->n_nodes = run;
+}
 // Level 0 with row-major output also paints the pixels of primary rays that missed
 // (bmp::Image::new's black), so the image needs no clearing pass.
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm, PrimaryGen pg, OutMap out) {
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm, PrimaryGen pg, OutMap out,
+                                                       UnitOrder* sort_uo) {
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
     __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
+    if (sort_uo && blockIdx.x == gridDim.x - 1) order_units(sort_uo);   // costs of the closest-hit launch just finished
     if (ctl->overflow) return;
     const uint32_t n = ctl->n_rays[qi];
     const uint32_t pool_base = ctl->pool_base;
@@ -436,7 +474,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             uint32_t total = 0;
             for (int k = 0; k < kShadeItems; ++k)
                 for (int j = 0; j < RTX_BLOCK / 64; ++j) total += cnt[k][j];
-            s_base = total ? atomicAdd(&ctl->n_nodes, total) : 0u;
+            s_base = wk.chunk_base ? wk.chunk_base[c0 / chunk] : (total ? atomicAdd(&ctl->n_nodes, total) : 0u);
         }
         __syncthreads();
         uint32_t run = s_base;
@@ -753,8 +791,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uin
 // material reflects or refracts, or depth 1), so a node's colour is final: it goes straight to
 // the image and the level bookkeeping of k_next_level is done here.
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples,
-                                                       OutMap out, int finalize) {
+                                                       OutMap out, int finalize, UnitOrder* sort_uo) {
     Ctl* ctl = wk.ctl;
+    if (sort_uo && blockIdx.x == gridDim.x - 1) order_units(sort_uo);   // costs of the shadow launch just finished
     if (ctl->overflow) return;
     const uint32_t nn = ctl->n_nodes;
     if (finalize && blockIdx.x == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
@@ -934,6 +973,13 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
     W_TRY(walloc(ctx, &wk.pC0, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.pC1, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.pLink, wk.cap_pool));
+    {
+        const size_t chunks = (size_t)wk.cap_rays / (RTX_BLOCK * kShadeItems) + 2;
+        W_TRY(walloc(ctx, &wk.chunk_cnt, chunks));
+        W_TRY(walloc(ctx, &wk.chunk_base, chunks));
+        if (hipMemsetAsync(wk.chunk_cnt, 0, chunks * sizeof(uint32_t), ctx->stream) != hipSuccess)
+            return rtx_fail(ctx, RTX_ERR_HIP, "hipMemsetAsync(chunk counts) failed");
+    }
     if (keys) W_TRY(walloc(ctx, &wk.pKey, wk.cap_pool));
     W_TRY(walloc(ctx, &wk.ctl, 1));
 #undef W_TRY
@@ -986,17 +1032,22 @@ PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
     const uint32_t blocks = trav_blocks(ctx, ((chunks + 3) / 4) * RTX_BLOCK);
     return PersistGrid{blocks, blocks * 4 * kChunk};
 }
-void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
-                    hipStream_t st) {
+// shade: the hits will be shaded, so they are counted per chunk and the node slots laid out (k_scan_chunks).
+// Returns false when the launch does not produce that layout (k_shade_a then allocates with an atomic).
+bool launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
+                    bool shade, hipStream_t st) {
     const DevScene& s = ctx->ds;
     if (ctx->opt_trace_variant == 0) {
-        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg, uo);
-        if (uo) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(kOrderThreads), 0, st, uo);
+        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg, uo,
+                           shade ? wk.chunk_cnt : nullptr);
+        if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
+        return shade;
     } else {
         if (pg.enabled)   // the persistent variant reads its rays from the queue
             hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_upper, 1u << 22)), dim3(RTX_BLOCK), 0, st, pg, wk, n_upper);
         const PersistGrid g = persist_grid(ctx, n_upper);
         hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);
+        return false;
     }
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
@@ -1009,7 +1060,6 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
         else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
         else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
         else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-        if (uo) hipLaunchKernelGGL(k_order_units, dim3(1), dim3(kOrderThreads), 0, st, uo);
     } else {
         const PersistGrid g = persist_grid(ctx, tasks_upper);
         if (any) hipLaunchKernelGGL(k_shadow_p<true>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
@@ -1122,7 +1172,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         int qi = 0;
         uint32_t n_rays = n, levels_done = 0;
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
-            launch_closest(ctx, wk, 0, n_rays, gen, nullptr, st);
+            launch_closest(ctx, wk, 0, n_rays, gen, nullptr, false, st);
         for (uint32_t level = 0; level < levels; ++level) {
             hipEvent_t a = ev.next(), b = ev.next();
             if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -1130,23 +1180,27 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             const PrimaryGen& pg = (level == 0) ? gen : no_gen;
             // level-0 launches of unchanged size reuse the unit costs of the previous frame (see UnitOrder)
             const bool ordered = level == 0 && cur_batch == batch;
-            launch_closest(ctx, wk, qi, n_rays, pg, ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr, st);
+            UnitOrder* uo0 = ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr;
+            UnitOrder* uo1 = nullptr;
+            const bool laid_out = launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st);
+            Work wk_a = wk;
+            if (!laid_out) wk_a.chunk_base = nullptr;
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
-                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map);
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk_a, qi,
+                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
                 RTX_HIP(ctx, hipEventRecord(c, st));
                 const uint64_t tasks = (uint64_t)n_rays * n_slots;
-                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow,
-                              ordered ? unit_order(ctx, 1, n_batches - 1, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup) : nullptr, st);
+                uo1 = ordered ? unit_order(ctx, 1, n_batches - 1, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup) : nullptr;
+                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st);
                 RTX_HIP(ctx, hipEventRecord(d, st));
                 shadow_events.emplace_back(c, d);
             }
             hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
-                               out_map, single_level ? 1 : 0);
+                               out_map, single_level ? 1 : 0, uo1);
             if (single_level) break;
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
             levels_done = level + 1;
@@ -1235,7 +1289,7 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
         hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0, 1);
         const PrimaryGen gen{cam, first, 0u, 1u, tiles_x, (uint32_t)n_tiles, 1u};
         hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, gen, wk, n);   // k_primary_out reads the directions
-        launch_closest(ctx, wk, 0, n, gen, nullptr, st);
+        launch_closest(ctx, wk, 0, n, gen, nullptr, false, st);
         hipLaunchKernelGGL(k_primary_out, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, wk.q[0], first, n, w, h, tiles_x,
                            d_prim, d_t, d_dir);
     }
