@@ -431,40 +431,51 @@ __device__ __forceinline__ uint32_t step_exponent(float extent) {
     return (uint32_t)min(max(ex + 127, 1), 254);
 }
 
-// Emits the 4-wide traversal nodes: every inner node of the binary tree at EVEN depth
-// absorbs its two children (where they are inner nodes themselves) and so gets 2-4
-// children; odd-depth inner nodes disappear. Child boxes are quantised to 8 bits per
-// plane relative to the node's own box, rounded outward and verified with the same
-// fma the traversal uses, so a quantised box always contains the padded box.
-__global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict__ child_l, const int* __restrict__ child_r,
-                                                     const int* __restrict__ parent, const int* __restrict__ rng_first,
+// Emits the 4-wide traversal nodes, top down, one level of the 4-wide tree per launch. A
+// traversal node is rooted at a binary node i (and stored at nodes[i]); its children start
+// as i's two children, and while there are fewer than four, the child with the largest
+// surface area that is still an inner node is replaced by its own two children -- the big
+// boxes are the ones a ray is most likely to enter, so opening them here saves a step there.
+// Children that remain inner nodes root the traversal nodes of the next level (qout).
+// Child boxes are quantised to 8 bits per plane relative to the node's own box, rounded
+// outward and verified with the same fma the traversal uses, so a quantised box always
+// contains the padded box.
+__device__ __forceinline__ float half_area(const float4& mn, const float4& mx) {
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
+                                                     int* __restrict__ qout, uint32_t* __restrict__ qout_count,
+                                                     const int* __restrict__ child_l, const int* __restrict__ child_r,
+                                                     const int* __restrict__ rng_first,
                                                      const int* __restrict__ rng_last, const float4* __restrict__ nmin,
                                                      const float4* __restrict__ nmax, BvhNode* __restrict__ nodes,
                                                      uint32_t* __restrict__ counts, int leaf_max) {
     __shared__ uint32_t s_nodes, s_leaves;
     if (threadIdx.x == 0) s_nodes = s_leaves = 0;
     __syncthreads();
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t slot = blockIdx.x * kThreads + threadIdx.x;
     uint32_t my_nodes = 0, my_leaves = 0;
-    bool emit = i < n - 1 && (rng_last[i] - rng_first[i] + 1) > leaf_max;
+    const bool emit = slot < *qin_count;
     if (emit) {
-        int depth = 0;
-        for (int p = parent[i]; p >= 0; p = parent[p]) ++depth;
-        emit = (depth & 1) == 0;
-    }
-    if (emit) {
-        int ch[4];
-        int nc = 0;
-        const int lr[2] = {child_l[i], child_r[i]};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = lr[k];
-            if (is_expandable(c, n, rng_first, rng_last, leaf_max)) {
-                ch[nc++] = child_l[c];
-                ch[nc++] = child_r[c];
-            } else {
-                ch[nc++] = c;
+        const int i = qin[slot];
+        int ch[4] = {child_l[i], child_r[i], 0, 0};
+        int nc = 2;
+        while (nc < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int k = 0; k < nc; ++k) {
+                if (!is_expandable(ch[k], n, rng_first, rng_last, leaf_max)) continue;
+                const float a = half_area(nmin[ch[k]], nmax[ch[k]]);
+                if (!(a <= best_area)) {   // also takes a NaN area rather than stopping early
+                    best = k;
+                    best_area = a;
+                }
             }
+            if (best < 0) break;
+            const int c = ch[best];
+            ch[best] = child_l[c];
+            ch[nc++] = child_r[c];
         }
         const float4 bmn = nmin[i], bmx = nmax[i];
         const float org[3] = {bmn.x, bmn.y, bmn.z};
@@ -510,7 +521,10 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
             }
         }
         int ref[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nc; ++k) ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves, leaf_max);
+        for (int k = 0; k < nc; ++k) {
+            ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves, leaf_max);
+            if (ref[k] >= 0) qout[atomicAdd(qout_count, 1u)] = ref[k];   // roots a node of the next level
+        }
         BvhNode nd;
         nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
                           eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (spheres ? 0x80000000u : 0u));
@@ -632,6 +646,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     pp.rel = s.pad_rel;
 
     const int leaf_max = std::min<int>(std::max<int>(ctx->opt_tune[3], 1), 8);
+    uint32_t levels4 = 0;   // height of the 4-wide tree
     const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > (uint32_t)leaf_max)
                         : (ctx->opt_force_mode == 1) ? false : (n > RTX_EXHAUSTIVE_MAX);
     if (!want_bvh) {
@@ -724,8 +739,26 @@ int rtx_bvh_build(rtx_context* ctx) {
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
         TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
-        hipLaunchKernelGGL(k_emit4, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, child_l, child_r,
-                           parent, rng_first, rng_last, nmin, nmax, nodes, counts, leaf_max);
+        // Emission: one launch per level of the 4-wide tree, from the root down (the refit queues are free now).
+        {
+            const int root = 0;
+            const uint32_t one = 1;
+            q = 0;
+            TRY_HIP(hipMemcpyAsync(queue[0], &root, 4, hipMemcpyHostToDevice, st));
+            TRY_HIP(hipMemcpyAsync(&qcount[0], &one, 4, hipMemcpyHostToDevice, st));
+            for (;;) {
+                uint32_t cnt = 0;
+                TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
+                TRY_HIP(hipStreamSynchronize(st));
+                if (cnt == 0) break;
+                if (++levels4 > 4096) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
+                TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
+                hipLaunchKernelGGL(k_emit4, dim3((cnt + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, queue[q], &qcount[q],
+                                   queue[q ^ 1], &qcount[q ^ 1], child_l, child_r, rng_first, rng_last, nmin, nmax, nodes, counts,
+                                   leaf_max);
+                q ^= 1;
+            }
+        }
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
         uint32_t hcounts[2] = {0, 0};
         uint8_t root_h = 0;
@@ -740,12 +773,10 @@ int rtx_bvh_build(rtx_context* ctx) {
         s.nodes = nodes;
         s.uses_bvh = 1;
     }
-    // Spill area of the per-lane traversal stacks (see TravStack): a 4-wide level pushes at most 3
-    // entries, the 4-wide tree is at most as high as the binary one; with transparent materials the
+    // Spill area of the per-lane traversal stacks (see TravStack): a 4-wide level pushes at most 3 entries; with transparent materials the
     // top 8 * RTX_MAX_DEPTH entries hold the suspended calls of a shadow ray's recursion.
     {
-        const uint32_t height = s.uses_bvh ? bs.max_depth : 0;
-        const uint32_t need = 3 * ((height + 1) / 2 + 1) + 4;
+        const uint32_t need = 3 * (levels4 + 1) + 4;   // levels4: height of the 4-wide tree (0 without a BVH)
         s.spill_entries = (need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0) + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
         s.spill_stride = ctx->num_cus * 8 * 256;
         int* spill = nullptr;

@@ -199,10 +199,10 @@ RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const Ra
             nx -= wx; ny -= wy; nz -= wz;
             fx += wx; fy += wy; fz += wz;
         }
-        const float lo = fmaxf(fmaxf(nx, ny), nz);
-        const float hi = fminf(fminf(fx, fy), fz);
-        // bitwise: all four children are tested without branches
-        const bool hit = ((uint32_t)k < nchild) & (lo <= hi) & (hi >= 0.0f) & (lo <= limit);
+        // [lo, hi] = the ray's parameter range inside the box, cut to [0, limit]: one comparison decides
+        const float lo = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
+        const float hi = fminf(fminf(fminf(fx, fy), fz), limit);
+        const bool hit = ((uint32_t)k < nchild) & (lo <= hi);   // bitwise: no branches
         t[k] = hit ? lo : inf;
     }
 }

@@ -137,6 +137,31 @@ def test_cooperative_traversal_is_exact(kind, rtx, synth):
     assert sa.traced_rays == sb.traced_rays and sa.shadow_rays == sb.shadow_rays
 
 
+def test_cost_ordered_units_do_not_change_the_frame(rtx, synth):
+    """Traversal launches hand out their work units most expensive first, from the durations the
+    previous frame recorded. Any order must give the same image and ray counts: frames 1..4 with
+    the option on (index order, then three learned orders) against a frame with it off."""
+    flat = synth.heightfield_scene(160, spec=0.3, glass_lattice=4)
+    w, h = 640, 360
+    with rtx.Context(0) as ctx:
+        ctx.set_option("cost_order", 0)
+        ctx.set_scene(flat)
+        ctx.build()
+        ref, sr = ctx.render(w, h, 4, 10)
+        ctx.set_option("cost_order", 1)
+        ctx.set_option("batch_pixels", 1 << 17)      # two batches: each keeps its own costs
+        for _ in range(4):
+            img, st = ctx.render(w, h, 4, 10)
+            assert np.array_equal(img, ref)
+            assert (st.shadow_rays, st.reflect_rays, st.refract_rays, st.shaded_nodes) == \
+                (sr.shadow_rays, sr.reflect_rays, sr.refract_rays, sr.shaded_nodes)
+            assert st.batches == 2
+        other, _ = ctx.render(w // 2, h, 4, 10)      # another size: recorded unit counts do not match, index order again
+        ctx.set_option("cost_order", 0)
+        other_ref, _ = ctx.render(w // 2, h, 4, 10)
+        assert np.array_equal(other, other_ref)
+
+
 def test_render_device_writes_the_same_row_major_frame(big):
     """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
     import torch
