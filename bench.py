@@ -55,7 +55,6 @@ def main():
     ap.add_argument("--glass", type=int, default=0)
     ap.add_argument("--cpu-stride", type=int, default=28, help="CPU baseline samples every n-th pixel in x and y (28: about 15 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="traversal kernel variant (rtx_set_option trace_variant)")
     ap.add_argument("--tune", type=str, default="", help="comma-separated tune0..3 overrides (experiments)")
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
@@ -96,8 +95,6 @@ def main():
     bcast_ms = (time.time() - t_b0) * 1e3
 
     ctx = rtx.Context(dev_index)
-    if args.variant:
-        ctx.set_option("trace_variant", args.variant)
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
         ctx.set_option("tune%d" % i, int(v))
     ctx.set_scene(flat)

@@ -148,11 +148,9 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "force_mode"   0 = automatic, 1 = exhaustive kernel, 2 = BVH (takes effect at the next rtx_build)
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^22)
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
- *   "trace_variant" 0 = one ray per lane with wavefront-cooperative work sharing (default), 1 = persistent wavefronts with lane refill
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
  *   "tune2"         traversal workgroups per CU (1..8, default 4)
  *   "tune3"         primitives per leaf (1..8, default 1; at the next rtx_build)
- *   "tune1"         phase-vote weight of variant 1
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.
  *   "stamps"        1 = traversal kernels record per-wavefront time stamps (see rtx_debug_stamps); at the next rtx_build */

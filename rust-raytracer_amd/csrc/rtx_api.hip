@@ -121,9 +121,6 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "force_mode must be 0, 1 or 2");
         ctx->opt_force_mode = value;
         ctx->built = false;   // takes effect at the next rtx_build
-    } else if (k == "trace_variant") {
-        if (value < 0 || value > 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "trace_variant must be 0 or 1");
-        ctx->opt_trace_variant = value;
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];

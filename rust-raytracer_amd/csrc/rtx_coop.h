@@ -7,8 +7,7 @@
 // memory access after the other, while the other lanes (and, at the end of a launch,
 // most of the device) wait. A traversal stack, however, is a list of independent
 // subtrees. So the query runs in two phases:
-//   1. every lane traverses for its own ray, results in registers (as trace_bvh_closest /
-//      trace_any do), until fewer than `threshold` lanes of the wavefront still have work;
+//   1. every lane traverses for its own ray, results in registers, until fewer than `threshold` lanes of the wavefront still have work;
 //   2. the lanes publish their results to a per-ray slot in LDS and idle lanes take over
 //      subtrees from busy lanes: a lane with more than one pending entry gives its OLDEST
 //      stack entry (the largest subtree) to an idle lane, together with the ray (ds_bpermute).
@@ -53,7 +52,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             cur = 0;
         }
     }
-    // any-hit: boxes beyond the light never hold an occluder (see trace_any)
+    // any-hit: boxes beyond the light never hold an occluder (vdistance(o, o + d*t) carries an absolute rounding error of a few ulp of |o|)
     float t_limit = __builtin_inff();
     if (ANY && dist_light >= 0.0f) {
         const float len = vlength(d);

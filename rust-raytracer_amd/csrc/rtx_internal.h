@@ -87,7 +87,7 @@ struct DevScene {
     int* spill;                 // [spill_entries][spill_stride] overflow of the per-lane traversal stacks
     uint32_t spill_stride;      // thread slots = largest traversal grid * 256
     uint32_t spill_entries;
-    int32_t tune[4];            // traversal tuning: [0] idle lanes that trigger a refill, [1] phase-vote weight (1/16ths)
+    int32_t tune[4];            // traversal tuning: [0] busy lanes below which a wavefront shares work, [2] workgroups per CU, [3] leaf size
     unsigned long long* stamps; // diagnostics: [2 kinds][spill_stride / 64 wavefronts][4], or nullptr
 };
 
@@ -135,7 +135,6 @@ struct rtx_context {
     int64_t opt_force_mode = 0;   // 0 auto, 1 exhaustive, 2 bvh
     int64_t opt_batch_pixels = 1 << 22;
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
-    int64_t opt_trace_variant = 0; // 0: one ray per lane, grid-stride; 1: persistent wavefronts with lane refill
     uint32_t num_cus = 256;
     int32_t opt_tune[4] = {48, 8, 4, RTX_LEAF_MAX};
     int64_t opt_stamps = 0;

@@ -18,7 +18,6 @@
 #include <utility>
 
 #include "rtx_coop.h"
-#include "rtx_persist.h"
 #include "rtx_shading.h"
 
 namespace {
@@ -28,7 +27,7 @@ struct Ctl {
     uint32_t n_nodes;
     uint32_t pool_base;
     uint32_t overflow;
-    uint32_t work_head[2];   // dynamic work counters of the persistent traversal kernels (closest, shadow)
+    uint32_t pad0[2];
     uint32_t pad[1];
     uint32_t unit_head[2][8][32];   // per-shard work counters (closest, shadow), one 128-byte line each
     uint32_t level_start[RTX_MAX_DEPTH + 2];
@@ -128,7 +127,6 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback, int first) {
         else ctl->saved[k] = ctl->stat[k];
     }
     ctl->overflow = 0;
-    ctl->work_head[0] = ctl->work_head[1] = 0;
     for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[0] = n;
     ctl->n_rays[1] = 0;
@@ -412,9 +410,10 @@ RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as
 
 // Forward step 1: every hit becomes a shading node (shade_intersection is only
 // entered for hits: lib.rs:264-271, 232-236, 243-247). A workgroup takes a chunk of
-// 256 * kShadeItems consecutive rays, counts its hits first and reserves their node
-// slots with ONE atomic, so the node order follows the ray order inside a chunk and
-// the global counter sees ~n/2048 atomics instead of one per wavefront.
+// 256 * kShadeItems consecutive rays; the chunk's first node slot is the number of hits in
+// the chunks before it (k_scan_chunks over the counts the traversal kernel took), and inside
+// the chunk slots follow the ray order, so the node order is the ray order: no atomics, and
+// the same frame gives the same order every time.
 constexpr int kShadeItems = 8;
 static_assert(RTX_BLOCK * kShadeItems == 64 * 32, "a chunk of k_shade_a is 32 units of the closest-hit kernel");
 
@@ -470,12 +469,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             if (lane == 0) cnt[k][w] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
-            for (int k = 0; k < kShadeItems; ++k)
-                for (int j = 0; j < RTX_BLOCK / 64; ++j) total += cnt[k][j];
-            s_base = wk.chunk_base ? wk.chunk_base[c0 / chunk] : (total ? atomicAdd(&ctl->n_nodes, total) : 0u);
-        }
+        if (threadIdx.x == 0) s_base = wk.chunk_base[c0 / chunk];   // slots of this chunk's hits: prefix of the chunks before it
         __syncthreads();
         uint32_t run = s_base;
         bool panic = false;
@@ -717,76 +711,6 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
     if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
 }
 
-// ---- persistent-wavefront variants of the two traversal kernels (rtx_persist.h), variant 1 ----
-struct TraceJob {
-    RayQueue q;
-    uint32_t item;
-    RTX_D bool start(uint32_t i, V3& o, V3& d, float&) {
-        const float4 o4 = q.o[i], d4 = q.d[i];
-        if (!(f2u(d4.w) & RTX_RAY_VALID)) {
-            q.hit[i] = make_uint2(0xffffffffu, 0u);
-            return false;
-        }
-        item = i;
-        o = v3(o4.x, o4.y, o4.z);
-        d = v3(d4.x, d4.y, d4.z);
-        return true;
-    }
-    RTX_D bool finish(const Trav& tr, V3&, V3&, float&) {
-        const bool hit = tr.best_id != 0x7fffffff;
-        q.hit[item] = make_uint2(hit ? (uint32_t)tr.best_id : 0xffffffffu, f2u(hit ? tr.best_t : 0.0f));
-        return false;
-    }
-};
-
-__global__ __launch_bounds__(RTX_BLOCK) void k_trace_p(DevScene s, RayQueue q, Ctl* ctl, int qi, uint32_t first_dynamic) {
-    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
-    if (ctl->overflow) return;
-    TravStack st;
-    st.set(lds, s);
-    TraceJob job;
-    job.q = q;
-    persistent_trace<false>(s, job, st, ctl->n_rays[qi], &ctl->work_head[0], first_dynamic);
-}
-
-template <bool ANY>
-struct ShadowJob {
-    ShadowTask<false> task;
-    RTX_D bool start(uint32_t item, V3& o, V3& d, float& dl) { return task.start(item, o, d, dl); }
-    RTX_D bool finish(const Trav& tr, V3& o, V3& d, float& dl) {
-        if (ANY) {
-            task.finish_any(tr.best_id != 0);
-            return false;
-        }
-        o = tr.o;
-        d = tr.d;
-        dl = -1.0f;
-        return task.finish_closest(tr.best_id == 0x7fffffff ? -1 : tr.best_id, tr.best_t, o, d);
-    }
-};
-
-template <bool ANY>
-__global__ __launch_bounds__(RTX_BLOCK) void k_shadow_p(DevScene s, Work wk, uint32_t depth, uint32_t first_dynamic) {
-    __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
-    Ctl* ctl = wk.ctl;
-    if (ctl->overflow) return;
-    TravStack st;
-    st.set(lds, s);
-    ShadowJob<ANY> job;
-    job.task.s = &s;
-    job.task.wk = wk;
-    job.task.nn = min(ctl->n_nodes, wk.cap_rays);
-    job.task.pool_base = ctl->pool_base;
-    job.task.depth = depth;
-    job.task.st = &st;
-    job.task.rays = 0;
-    const uint64_t total = (uint64_t)job.task.nn * s.n_lights;
-    persistent_trace<ANY>(s, job, st, (uint32_t)min(total, (uint64_t)0xfffffff0u), &ctl->work_head[1], first_dynamic);
-    unsigned long long rays = job.task.rays;
-    for (int o = 32; o > 0; o >>= 1) rays += __shfl_xor(rays, o);
-    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctl->stat[ST_SHADOW], rays);
-}
-
 // Forward step 3: local colour and children. `finalize`: the frame has a single level (no
 // material reflects or refracts, or depth 1), so a node's colour is final: it goes straight to
 // the image and the level bookkeeping of k_next_level is done here.
@@ -875,7 +799,6 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
     ctl->pool_base += min(ctl->n_nodes, cap_rays);
     ctl->level_start[level + 1] = ctl->pool_base;
     ctl->n_nodes = 0;
-    ctl->work_head[0] = ctl->work_head[1] = 0;
     for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[q_consumed] = 0;
     if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
@@ -1022,49 +945,22 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items) {
     const uint64_t cap = (uint64_t)ctx->num_cus * (uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8);
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items + RTX_BLOCK - 1) / RTX_BLOCK, cap));
 }
-// Persistent launches: one chunk of kChunk items per wavefront is assigned statically (wave w
-// starts with chunk w); further chunks come from the atomic counter, offset by first_dynamic.
-struct PersistGrid {
-    uint32_t blocks, first_dynamic;
-};
-PersistGrid persist_grid(const rtx_context* ctx, uint64_t items_upper) {
-    const uint64_t chunks = (items_upper + kChunk - 1) / kChunk;
-    const uint32_t blocks = trav_blocks(ctx, ((chunks + 3) / 4) * RTX_BLOCK);
-    return PersistGrid{blocks, blocks * 4 * kChunk};
-}
 // shade: the hits will be shaded, so they are counted per chunk and the node slots laid out (k_scan_chunks).
-// Returns false when the launch does not produce that layout (k_shade_a then allocates with an atomic).
-bool launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
+void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st) {
-    const DevScene& s = ctx->ds;
-    if (ctx->opt_trace_variant == 0) {
-        hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, pg, uo,
-                           shade ? wk.chunk_cnt : nullptr);
-        if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
-        return shade;
-    } else {
-        if (pg.enabled)   // the persistent variant reads its rays from the queue
-            hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_upper, 1u << 22)), dim3(RTX_BLOCK), 0, st, pg, wk, n_upper);
-        const PersistGrid g = persist_grid(ctx, n_upper);
-        hipLaunchKernelGGL(k_trace_p, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk.q[qi], wk.ctl, qi, g.first_dynamic);
-        return false;
-    }
+    hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo,
+                       shade ? wk.chunk_cnt : nullptr);
+    if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
                    UnitOrder* uo, hipStream_t st) {
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
-    if (ctx->opt_trace_variant == 0 || area) {   // the persistent variant has no sample slots
-        const dim3 grid(trav_blocks(ctx, tasks_upper)), block(RTX_BLOCK);
-        if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-        else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-        else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-        else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-    } else {
-        const PersistGrid g = persist_grid(ctx, tasks_upper);
-        if (any) hipLaunchKernelGGL(k_shadow_p<true>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
-        else hipLaunchKernelGGL(k_shadow_p<false>, dim3(g.blocks), dim3(RTX_BLOCK), 0, st, s, wk, depth, g.first_dynamic);
-    }
+    const dim3 grid(trav_blocks(ctx, tasks_upper)), block(RTX_BLOCK);
+    if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+    else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+    else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
 }
 
 // The cost / order buffer of one (kind, batch) pair of level-0 launches; nullptr when the
@@ -1182,12 +1078,10 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             const bool ordered = level == 0 && cur_batch == batch;
             UnitOrder* uo0 = ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr;
             UnitOrder* uo1 = nullptr;
-            const bool laid_out = launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st);
-            Work wk_a = wk;
-            if (!laid_out) wk_a.chunk_base = nullptr;
+            launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st);
             RTX_HIP(ctx, hipEventRecord(b, st));
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk_a, qi,
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
                                PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();

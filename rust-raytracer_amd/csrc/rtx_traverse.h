@@ -321,34 +321,6 @@ RTX_D Fetched fetch_ref(const DevScene& s, int cur) {
 }
 RTX_D float4 as_f4(uint4 u) { return make_float4(u2f(u.x), u2f(u.y), u2f(u.z), u2f(u.w)); }
 
-// Closest hit through the BVH. Returns best_id = -1 on a miss.
-RTX_D void trace_bvh_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float& best_t, int& best_id) {
-    if (!in_safe_region(s, o)) {
-        trace_exhaustive(s, o, d, best_t, best_id);
-        return;
-    }
-    best_t = __builtin_inff();
-    best_id = 0x7fffffff;
-    const RayBox rb = make_raybox(s, o, d);
-    int cur = 0, sp = 0;
-    while (cur != kRefDone) {
-        const Fetched f = fetch_ref(s, cur);
-        if (cur >= 0) {
-            cur = node4_step(f.a, f.b, f.c, f.d, rb, o, best_t, st, sp, 0, kRefDone);
-        } else {
-            const uint32_t leaf = ~(uint32_t)cur;
-            const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
-            for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
-#ifdef RTX_COUNT_STEPS
-            st.leaves += cnt;
-#endif
-            cur = (sp == 0) ? kRefDone : st.get(--sp);
-        }
-    }
-    if (best_id == 0x7fffffff) best_id = -1;
-}
-
 // Shadow-ray occlusion for scenes without transparent materials. The reference
 // (src/lib.rs:117-135) takes the closest hit and reports "lit" iff it is farther
 // from the ray origin than the light (`ori.distance(hit) > ori.distance(light)`),
@@ -367,42 +339,4 @@ RTX_D bool any_quads(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist_lig
 }
 RTX_D bool any_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float dist_light) {
     return any_quads(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, dist_light);
-}
-RTX_D bool trace_any(const DevScene& s, V3 o, V3 d, float dist_light, TravStack& st) {
-    if (!s.uses_bvh || !in_safe_region(s, o)) {
-        for (uint32_t i = 0; i < s.n_prims; ++i)
-            if (any_record(s.recs, i, o, d, dist_light)) return true;
-        return false;
-    }
-    // Box culling bound: hits beyond the light never occlude. |d| is ~1 for point
-    // lights (Light::get_dir normalises) but is kept general.
-    float t_limit = __builtin_inff();
-    if (dist_light >= 0.0f) {
-        // vdistance(o, o + d*t) carries an absolute rounding error of a few ulp of |o|.
-        const float len = vlength(d);
-        const float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-        t_limit = (len > 0.0f) ? ((dist_light + 4e-6f * m) / len) * 1.0001f + 1e-6f : __builtin_inff();
-    }
-    const RayBox rb = make_raybox(s, o, d);
-    int cur = 0, sp = 0;
-    while (cur != kRefDone) {
-        const Fetched f = fetch_ref(s, cur);
-        if (cur >= 0) {
-            cur = node4_step<false>(f.a, f.b, f.c, f.d, rb, o, t_limit, st, sp, 0, kRefDone);
-        } else {
-            const uint32_t leaf = ~(uint32_t)cur;
-            const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
-            if (any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light)) return true;
-            for (uint32_t k = 1; k < cnt; ++k)
-                if (any_record(s.recs, first + k, o, d, dist_light)) return true;
-            cur = (sp == 0) ? kRefDone : st.get(--sp);
-        }
-    }
-    return false;
-}
-
-// Closest hit in either mode.
-RTX_D void trace_closest(const DevScene& s, V3 o, V3 d, TravStack& st, float& best_t, int& best_id) {
-    if (s.uses_bvh) trace_bvh_closest(s, o, d, st, best_t, best_id);
-    else trace_exhaustive(s, o, d, best_t, best_id);
 }
