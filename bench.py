@@ -103,25 +103,40 @@ def main():
     build = ctx.build()
     w, h = args.width, args.height
     tpr = rtx.tiles_per_rank(w, h, world)
-    slab = torch.zeros(tpr * 192, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) if world > 1 else slab
+    # Double-buffered slabs: the all-gather of frame k travels while frame k + 1 is rendered.
+    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
     image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+    pending = []   # [(work, buffer index)] of the frame whose slabs are still travelling
+
+    def finish_pending():
+        while pending:
+            work, idx = pending.pop()
+            work.wait()
+            torch.cuda.current_stream().synchronize()
+            ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+
+    step_no = [0]
 
     def step():
         if world == 1:   # single GPU: the frame is written row-major in place
             return ctx.render_device(w, h, args.depth, 10, image.data_ptr())
-        st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slab.data_ptr())
+        cur = step_no[0] & 1
+        step_no[0] += 1
+        st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slabs[cur].data_ptr())
+        finish_pending()          # the previous frame's slabs arrived while this one was rendered
         if gloo:
-            dist.all_gather_into_tensor(gathered_host, slab.cpu())
-            gathered.copy_(gathered_host)
+            dist.all_gather_into_tensor(gathered_host, slabs[cur].cpu())
+            gathered[cur].copy_(gathered_host)
+            torch.cuda.current_stream().synchronize()
+            ctx.assemble_tiles(w, h, world, gathered[cur].data_ptr(), image.data_ptr())
         else:
-            dist.all_gather_into_tensor(gathered, slab)
-        torch.cuda.current_stream().synchronize()
-        ctx.assemble_tiles(w, h, world, gathered.data_ptr(), image.data_ptr())
+            pending.append((dist.all_gather_into_tensor(gathered[cur], slabs[cur], async_op=True), cur))
         return st
 
     def sync():
+        finish_pending()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
