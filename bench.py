@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
                          "collectives through host memory, ranks may share a GPU)")
+    ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
     if args.lib:
@@ -95,6 +96,8 @@ def main():
     bcast_ms = (time.time() - t_b0) * 1e3
 
     ctx = rtx.Context(dev_index)
+    if args.no_cost_order:
+        ctx.set_option("cost_order", 0)
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
         ctx.set_option("tune%d" % i, int(v))
     ctx.set_scene(flat)
