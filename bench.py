@@ -113,11 +113,15 @@ def main():
     image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
     pending = []   # [(work, buffer index)] of the frame whose slabs are still travelling
 
+    gather_wait = [0.0]   # seconds the host waited for slabs that had not arrived when the next frame was done
+
     def finish_pending():
         while pending:
             work, idx = pending.pop()
+            t_w = time.perf_counter()
             work.wait()
             torch.cuda.current_stream().synchronize()
+            gather_wait[0] += time.perf_counter() - t_w
             ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
 
     step_no = [0]
@@ -148,6 +152,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    gather_wait[0] = 0.0
     acc = {"closest_ms": 0.0, "shadow_ms": 0.0, "closest_launches": 0, "shadow_launches": 0, "render_ms": 0.0,
            "closest_rays": 0, "shadow_rays": 0, "traced": 0, "reference": 0}
     t0 = time.perf_counter()
@@ -219,6 +224,7 @@ def main():
             "sharded_frame_equals_single_gpu_frame": sharded_equal,
             "device_frame_ms_rank0": acc["render_ms"] / args.steps,
             "build_ms": build["build_ms"], "upload_ms": build["upload_ms"], "scene_broadcast_ms": bcast_ms,
+            "gather_wait_ms_per_step_rank0": (gather_wait[0] / args.steps * 1e3) if world > 1 else None,
             "bvh": {k: build[k] for k in ("n_nodes", "n_leaves", "max_depth", "key_bits", "uses_bvh")},
             "kernels": {"closest_ms": acc["closest_ms"] / max(acc["closest_launches"], 1),
                         "shadow_ms": acc["shadow_ms"] / max(acc["shadow_launches"], 1)},
