@@ -59,9 +59,17 @@ def main():
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
                          "collectives through host memory, ranks may share a GPU)")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5),
+                    help="BASELINE configuration: 3 = 1M triangles at 1080p (default, the single-GPU bench workload), 4 = 16M triangles + "
+                         "64 glass spheres at 4K depth 5, 5 = 62.72M triangles + 1.28M spheres at 8K depth 5")
     ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
+    small_spheres = 0
+    if args.config == 4:
+        args.grid, args.width, args.height, args.depth, args.spec, args.glass = 2829, 3840, 2160, 5, 0.3, 8
+    elif args.config == 5:
+        args.grid, args.width, args.height, args.depth, args.spec, small_spheres = 5600, 7680, 4320, 5, 0.3, 1280000
     if args.lib:
         os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", args.lib)
 
@@ -89,7 +97,7 @@ def main():
     synth = importlib.import_module("rust-raytracer_amd.synth")
     rdist = importlib.import_module("rust-raytracer_amd.dist")
 
-    flat = synth.heightfield_scene(args.grid, spec=args.spec, glass_lattice=args.glass) if rank == 0 else None
+    flat = synth.heightfield_scene(args.grid, spec=args.spec, glass_lattice=args.glass, small_spheres=small_spheres) if rank == 0 else None
     t_b0 = time.time()
     if world > 1:
         flat = rdist.broadcast_scene(flat, 0, cdev)
@@ -197,7 +205,9 @@ def main():
         achieved = rays_per_launch * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        default_workload = (args.config == 3 and args.grid == 708 and (w, h) == (1920, 1080) and args.depth == 10
+                            and args.spec == 0.0 and args.glass == 0 and world == 1)
+        if default_workload and os.path.exists(tpath):   # the counters were collected on exactly this workload
             try:
                 with open(tpath) as f:
                     traffic = json.load(f)["kernels"]["shadow" if kname.startswith("k_shadow") else "closest"]["bytes_per_launch"]
@@ -216,8 +226,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic %d-triangle tessellated height field + 4 point lights at %dx%d, depth %d, "
-                                   "LBVH traversal, scene and BVH resident in HBM" % (flat.n_tris, w, h, args.depth),
+            "config": {"workload": "synthetic %d-triangle tessellated height field%s + 4 point lights at %dx%d, depth %d, "
+                                   "LBVH traversal, scene and BVH resident in HBM"
+                                   % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth,
                        "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if world > 1 else "single GPU"},
             "rays_per_frame": total_traced / args.steps,
