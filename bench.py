@@ -114,58 +114,25 @@ def main():
     build = ctx.build()
     w, h = args.width, args.height
     tpr = rtx.tiles_per_rank(w, h, world)
-    # Double-buffered slabs: the all-gather of frame k travels while frame k + 1 is rendered.
-    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    # Frames are pipelined: while the GPU renders frame k the host collects frame k - 1 (and, for
+    # N > 1, its slabs travel while frame k renders and frame k - 2 is assembled). Every frame that
+    # was enqueued inside the timed region is complete before the clock stops.
+    ring = 3
+    images = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
+    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
     gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
-    image = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
-    pending = []   # [(work, buffer index)] of the frame whose slabs are still travelling
+    image = images[0]
+    acc = {}
+    gather_wait = [0.0]   # seconds the host waited for slabs that had not arrived when they were needed
+    state = {"enqueued": 0, "collected": 0, "gather": None}
 
-    gather_wait = [0.0]   # seconds the host waited for slabs that had not arrived when the next frame was done
+    def reset_acc():
+        acc.update({"closest_ms": 0.0, "shadow_ms": 0.0, "closest_launches": 0, "shadow_launches": 0, "render_ms": 0.0,
+                    "closest_rays": 0, "shadow_rays": 0, "traced": 0, "reference": 0})
+        gather_wait[0] = 0.0
 
-    def finish_pending():
-        while pending:
-            work, idx = pending.pop()
-            t_w = time.perf_counter()
-            work.wait()
-            torch.cuda.current_stream().synchronize()
-            gather_wait[0] += time.perf_counter() - t_w
-            ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
-
-    step_no = [0]
-
-    def step():
-        if world == 1:   # single GPU: the frame is written row-major in place
-            return ctx.render_device(w, h, args.depth, 10, image.data_ptr())
-        cur = step_no[0] & 1
-        step_no[0] += 1
-        st = ctx.render_tiles(w, h, args.depth, 10, rank, world, slabs[cur].data_ptr())
-        finish_pending()          # the previous frame's slabs arrived while this one was rendered
-        if gloo:
-            dist.all_gather_into_tensor(gathered_host, slabs[cur].cpu())
-            gathered[cur].copy_(gathered_host)
-            torch.cuda.current_stream().synchronize()
-            ctx.assemble_tiles(w, h, world, gathered[cur].data_ptr(), image.data_ptr())
-        else:
-            pending.append((dist.all_gather_into_tensor(gathered[cur], slabs[cur], async_op=True), cur))
-        return st
-
-    def sync():
-        finish_pending()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    gather_wait[0] = 0.0
-    acc = {"closest_ms": 0.0, "shadow_ms": 0.0, "closest_launches": 0, "shadow_launches": 0, "render_ms": 0.0,
-           "closest_rays": 0, "shadow_rays": 0, "traced": 0, "reference": 0}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
+    def account(st):
         acc["closest_ms"] += st.closest_ms
         acc["shadow_ms"] += st.shadow_ms
         acc["closest_launches"] += st.closest_launches
@@ -175,8 +142,64 @@ def main():
         acc["shadow_rays"] += st.shadow_rays
         acc["traced"] += st.traced_rays
         acc["reference"] += st.reference_rays
+
+    def finish_gather():
+        if state["gather"] is None:
+            return
+        work, idx = state["gather"]
+        state["gather"] = None
+        t_w = time.perf_counter()
+        work.wait()
+        torch.cuda.current_stream().synchronize()
+        gather_wait[0] += time.perf_counter() - t_w
+        ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+
+    def collect():
+        """Collects the oldest frame in flight; for N > 1 sends its slab on its way."""
+        account(ctx.render_wait())
+        idx = state["collected"] % ring
+        state["collected"] += 1
+        if world == 1:
+            return
+        finish_gather()            # the frame before it
+        if gloo:
+            dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
+            gathered[idx].copy_(gathered_host)
+            torch.cuda.current_stream().synchronize()
+            ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+        else:
+            state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
+
+    def step():
+        k = state["enqueued"]
+        state["enqueued"] += 1
+        if world == 1:   # single GPU: the frame is written row-major in place
+            ctx.render_device_async(w, h, args.depth, 10, images[k & 1].data_ptr())
+        else:
+            ctx.render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
+        if state["enqueued"] - state["collected"] > 1:
+            collect()
+
+    def sync():
+        while state["collected"] < state["enqueued"]:
+            collect()
+        finish_gather()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    reset_acc()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    reset_acc()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
     sync()
     elapsed = time.perf_counter() - t0
+    image = images[(state["enqueued"] - 1) & 1] if world == 1 else image
     total_traced = acc["traced"]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

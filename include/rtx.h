@@ -204,6 +204,18 @@ int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth
 int rtx_render_device(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
                       uint8_t* d_rgb, rtx_render_stats* stats);
 
+/* Frames in flight (no counterpart in the reference, whose trace_rays returns the finished image):
+ * the _async calls enqueue a frame and return; rtx_render_wait collects the OLDEST enqueued frame
+ * (its image is complete, its statistics are returned). At most two frames may be waiting, so a
+ * caller alternates "enqueue frame k+1, collect frame k" and the device never idles between frames.
+ * Frames that need host decisions while they render (several batches or ray-tree levels) are simply
+ * rendered inside the _async call. Each frame in flight needs its own output buffer. */
+int rtx_render_device_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+                            uint8_t* d_rgb);
+int rtx_render_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples,
+                           uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles);
+int rtx_render_wait(rtx_context* ctx, rtx_render_stats* stats);
+
 /* Tile-sharded frame for one process per GPU. The image is cut into 8x8-pixel
  * tiles numbered row-major; this call renders tiles with
  * (tile_index % world) == rank. d_rgb_tiles is DEVICE memory receiving the

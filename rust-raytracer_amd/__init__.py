@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
-    "rtx_debug_stamps",
+    "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait",
 ]
 
 
@@ -146,6 +146,9 @@ def lib():
         L.rtx_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]
         L.rtx_stream.argtypes = [vp]
         L.rtx_stream.restype = vp
+        L.rtx_render_device_async.argtypes = [vp, u32, u32, u32, u32, vp]
+        L.rtx_render_tiles_async.argtypes = [vp, u32, u32, u32, u32, u32, u32, vp]
+        L.rtx_render_wait.argtypes = [vp, C.POINTER(RenderStats)]
         L.rtx_debug_stamps.argtypes = [vp, C.c_int, vp, u64]
         L.rtx_debug_stamps.restype = u64
         _lib = L
@@ -367,6 +370,19 @@ class Context:
         """d_rgb: device pointer (int) to height * width * 3 bytes, row-major."""
         st = RenderStats()
         self._check(self._L.rtx_render_device(self._h, width, height, depth, samples, d_rgb, C.byref(st)))
+        return st
+
+    def render_device_async(self, width, height, depth, samples, d_rgb):
+        """Enqueues a frame (see rtx_render_device_async); collect it with render_wait()."""
+        self._check(self._L.rtx_render_device_async(self._h, width, height, depth, samples, d_rgb))
+
+    def render_tiles_async(self, width, height, depth, samples, rank, world, d_rgb_tiles):
+        self._check(self._L.rtx_render_tiles_async(self._h, width, height, depth, samples, rank, world, d_rgb_tiles))
+
+    def render_wait(self):
+        """Collects the oldest frame in flight and returns its RenderStats."""
+        st = RenderStats()
+        self._check(self._L.rtx_render_wait(self._h, C.byref(st)))
         return st
 
     def render_tiles(self, width, height, depth, samples, rank, world, d_rgb_tiles):

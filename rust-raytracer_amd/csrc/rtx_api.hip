@@ -152,6 +152,7 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
         (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
         return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor has a NULL array with a non-zero count");
     RTX_HIP(ctx, hipSetDevice(ctx->device));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old scene
 
     // prim_ref: reference primitive id -> (kind, index); the id arrays must form a permutation.
     std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
@@ -254,6 +255,7 @@ int rtx_build(rtx_context* ctx, rtx_build_stats* stats) {
     if (!ctx) return RTX_ERR_INVALID_ARG;
     if (!ctx->has_scene) return rtx_fail(ctx, RTX_ERR_NO_SCENE, "no scene has been set (rtx_scene_set)");
     RTX_HIP(ctx, hipSetDevice(ctx->device));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old tree
     int rc = rtx_bvh_build(ctx);
     if (rc != RTX_OK) return rc;
     if (stats) *stats = ctx->build_stats;
@@ -344,6 +346,30 @@ int rtx_render_device(rtx_context* ctx, uint32_t width, uint32_t height, uint32_
     if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
     if (!d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb is NULL");
     return rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_rgb, stats, true);
+}
+
+int rtx_render_device_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* d_rgb) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (!d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb is NULL");
+    return rtx_render_async_impl(ctx, width, height, depth, samples, 0, 1, d_rgb, true);
+}
+
+int rtx_render_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint32_t rank,
+                           uint32_t world, uint8_t* d_rgb_tiles) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (world == 0 || rank >= world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rank must be below world");
+    if (!d_rgb_tiles) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb_tiles is NULL");
+    return rtx_render_async_impl(ctx, width, height, depth, samples, rank, world, d_rgb_tiles, false);
+}
+
+int rtx_render_wait(rtx_context* ctx, rtx_render_stats* stats) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    return rtx_render_wait_impl(ctx, stats);
 }
 
 int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* rgb,

@@ -138,6 +138,24 @@ struct rtx_context {
     uint32_t num_cus = 256;
     int32_t opt_tune[4] = {48, 8, 4, RTX_LEAF_MAX};
     int64_t opt_stamps = 0;
+
+    // Frames in flight (rtx_render_*_async / rtx_render_wait): a frame whose kernels need no host
+    // decision (one batch, one level) is only enqueued; its counters land in the slot's pinned
+    // block and are read when the frame is collected. Up to two frames wait in the ring.
+    struct AsyncSlot {
+        bool used = false, deferred = false;
+        rtx_render_stats stats{};                 // ready when !deferred
+        std::vector<hipEvent_t> events;           // this slot's own events (frames in flight must not share them)
+        hipEvent_t f0 = nullptr, f1 = nullptr, a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+        uint64_t primary = 0;
+        bool has_shadow = false;
+        // arguments, to render the frame again if its queues overflowed
+        uint32_t w = 0, h = 0, depth = 0, samples = 0, rank = 0, world = 1;
+        uint8_t* out = nullptr;
+        bool direct = false;
+    };
+    AsyncSlot async_slots[2];
+    uint32_t async_head = 0, async_count = 0;     // oldest slot, frames waiting
     int64_t opt_cost_order = 1;   // level-0 traversal launches hand out their units most expensive first (costs of the previous frame)
     std::vector<std::pair<uint64_t, void*>> order_bufs;   // (kind, batch, capacity) -> UnitOrder
 };
@@ -158,6 +176,10 @@ int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, cons
                          int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);
 // rtx_shade.hip
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
-                    uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct);
+                    uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct,
+                    int async_slot = -1);
+int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
+                          uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, bool direct);
+int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats);
 int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir);
 int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb);

@@ -915,6 +915,7 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
         std::memcpy(out, ctx->work_blob.data(), sizeof(Work));
         return RTX_OK;
     }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // frames in flight still use the old workspace
     for (void* p : ctx->work_allocs) (void)hipFree(p);
     ctx->work_allocs.clear();
     ctx->work_batch = 0;
@@ -970,17 +971,49 @@ inline uint32_t blocks_for(uint64_t n, uint32_t cap) {
 }
 
 struct EventPool {
-    rtx_context* ctx;
+    std::vector<hipEvent_t>* pool;
     size_t used = 0;
     hipEvent_t next() {
-        if (used == ctx->events.size()) {
+        if (used == pool->size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            ctx->events.push_back(e);
+            pool->push_back(e);
         }
-        return (hipEvent_t)ctx->events[used++];
+        return (*pool)[used++];
     }
 };
+
+// Counters and event times of a finished frame.
+void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
+                const std::vector<std::pair<hipEvent_t, hipEvent_t>>& closest_events,
+                const std::vector<std::pair<hipEvent_t, hipEvent_t>>& shadow_events, uint32_t n_batches, rtx_render_stats* stats) {
+    rtx_render_stats rs{};
+    rs.primary_rays = primary;
+    rs.shadow_rays = hc.stat[ST_SHADOW];
+    rs.reflect_rays = hc.stat[ST_REFLECT];
+    rs.refract_rays = hc.stat[ST_REFRACT];
+    rs.skipped_rays = hc.stat[ST_SKIPPED];
+    rs.shaded_nodes = hc.stat[ST_NODES];
+    rs.panic_pixels = hc.stat[ST_PANIC];
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, f0, f1);
+    rs.render_ms = ms;
+    auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs) {
+        float total = 0.0f;
+        for (auto& p : evs) {
+            float e = 0.0f;
+            (void)hipEventElapsedTime(&e, p.first, p.second);
+            total += e;
+        }
+        return total;
+    };
+    rs.closest_ms = sum_ms(closest_events);
+    rs.shadow_ms = sum_ms(shadow_events);
+    rs.closest_launches = (uint32_t)closest_events.size();
+    rs.shadow_launches = (uint32_t)shadow_events.size();
+    rs.batches = n_batches;
+    *stats = rs;
+}
 
 // Every traversal launch is bounded by the spill area: at most blocks_per_cu * CUs workgroups.
 uint32_t trav_blocks(const rtx_context* ctx, uint64_t items) {
@@ -1035,8 +1068,9 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
 }
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
-                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct) {
+                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct, int async_slot) {
     const DevScene& s = ctx->ds;
+    rtx_context::AsyncSlot* slot = (async_slot >= 0) ? &ctx->async_slots[async_slot] : nullptr;
     hipStream_t st = ctx->stream;
     if (depth > RTX_MAX_DEPTH) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "depth above RTX_MAX_DEPTH");
     // num_samples only multiplies area-light rays (lib.rs:219-222)
@@ -1070,10 +1104,10 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x};
     if (!ctx->pinned) {
         void* p = nullptr;
-        RTX_HIP(ctx, hipHostMalloc(&p, 8192, hipHostMallocDefault));
+        RTX_HIP(ctx, hipHostMalloc(&p, 4 * 4096, hipHostMallocDefault));
         ctx->pinned = p;
     }
-    Ctl* host_ctl = (Ctl*)ctx->pinned;
+    Ctl* host_ctl = (Ctl*)((char*)ctx->pinned + (slot ? (size_t)(2 + async_slot) * 4096 : 0));
     uint32_t* host_next = (uint32_t*)((char*)ctx->pinned + 4096);
     static_assert(sizeof(Ctl) <= 4096, "Ctl must fit the pinned staging area");
 
@@ -1091,7 +1125,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const CamSetup cam = make_cam(ctx->camera, w, h);
     const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
     const bool any_shadow = !s.has_transparent;
-    EventPool ev{ctx};
+    EventPool ev{slot ? &slot->events : &ctx->events};
     hipEvent_t f0 = ev.next(), f1 = ev.next();
     if (!f0 || !f1) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
     std::vector<std::pair<hipEvent_t, hipEvent_t>> closest_events, shadow_events;
@@ -1158,6 +1192,21 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         const bool last_batch = first + n >= rays_local;
         RTX_HIP(ctx, hipMemcpyAsync(host_ctl, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
         if (last_batch) RTX_HIP(ctx, hipEventRecord(f1, st));
+        if (slot && single_level && n_batches == 1 && last_batch) {
+            // Nothing in this frame needs the host: leave it in flight, rtx_render_wait collects it.
+            slot->deferred = true;
+            slot->f0 = f0;
+            slot->f1 = f1;
+            slot->a = closest_events[0].first;
+            slot->b = closest_events[0].second;
+            slot->has_shadow = !shadow_events.empty();
+            if (slot->has_shadow) {
+                slot->c = shadow_events[0].first;
+                slot->d = shadow_events[0].second;
+            }
+            slot->primary = primary;
+            return RTX_OK;
+        }
         RTX_HIP(ctx, wait_stream(st));
         if (host_ctl->overflow) {
             // The ray tree of this batch outgrew the queues: render the same pixels again in
@@ -1176,35 +1225,53 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         std::memset(host_ctl, 0, sizeof(Ctl));
     }
     RTX_HIP(ctx, hipGetLastError());
-    if (stats) {
-        const Ctl& hc = *host_ctl;   // read back with the last batch
-        rtx_render_stats rs{};
-        rs.primary_rays = primary;
-        rs.shadow_rays = hc.stat[ST_SHADOW];
-        rs.reflect_rays = hc.stat[ST_REFLECT];
-        rs.refract_rays = hc.stat[ST_REFRACT];
-        rs.skipped_rays = hc.stat[ST_SKIPPED];
-        rs.shaded_nodes = hc.stat[ST_NODES];
-        rs.panic_pixels = hc.stat[ST_PANIC];
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, f0, f1);
-        rs.render_ms = ms;
-        auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs) {
-            float total = 0.0f;
-            for (auto& p : evs) {
-                float e = 0.0f;
-                (void)hipEventElapsedTime(&e, p.first, p.second);
-                total += e;
-            }
-            return total;
-        };
-        rs.closest_ms = sum_ms(closest_events);
-        rs.shadow_ms = sum_ms(shadow_events);
-        rs.closest_launches = (uint32_t)closest_events.size();
-        rs.shadow_launches = (uint32_t)shadow_events.size();
-        rs.batches = n_batches;
-        *stats = rs;
+    if (stats) fill_stats(*host_ctl, primary, f0, f1, closest_events, shadow_events, n_batches, stats);
+    return RTX_OK;
+}
+
+// Enqueues a frame; at most two frames may be waiting to be collected.
+int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
+                          uint32_t world, uint8_t* d_rgb_tiles, bool direct) {
+    if (ctx->async_count >= 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "two frames are already in flight: collect one with rtx_render_wait");
+    const int idx = (int)((ctx->async_head + ctx->async_count) & 1u);
+    rtx_context::AsyncSlot& slot = ctx->async_slots[idx];
+    slot.used = true;
+    slot.deferred = false;
+    slot.w = w; slot.h = h; slot.depth = depth; slot.samples = samples; slot.rank = rank; slot.world = world;
+    slot.out = d_rgb_tiles;
+    slot.direct = direct;
+    const int rc = rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, &slot.stats, direct, idx);
+    if (rc != RTX_OK) {
+        slot.used = false;
+        return rc;
     }
+    ++ctx->async_count;
+    return RTX_OK;
+}
+
+// Collects the oldest frame in flight.
+int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats) {
+    if (ctx->async_count == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "no frame is in flight");
+    const int idx = (int)(ctx->async_head & 1u);
+    rtx_context::AsyncSlot& slot = ctx->async_slots[idx];
+    ctx->async_head ^= 1u;
+    --ctx->async_count;
+    slot.used = false;
+    if (slot.deferred) {
+        for (;;) {   // poll the frame's own end event: a later frame may already be queued behind it
+            const hipError_t e = hipEventQuery(slot.f1);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) return rtx_fail(ctx, RTX_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        }
+        const Ctl* hc = (const Ctl*)((char*)ctx->pinned + (size_t)(2 + idx) * 4096);
+        if (hc->overflow)   // rare: the frame's ray tree outgrew the queues; render it again the patient way
+            return rtx_render_impl(ctx, slot.w, slot.h, slot.depth, slot.samples, slot.rank, slot.world, slot.out, stats, slot.direct);
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ce{{slot.a, slot.b}}, se;
+        if (slot.has_shadow) se.emplace_back(slot.c, slot.d);
+        if (stats) fill_stats(*hc, slot.primary, slot.f0, slot.f1, ce, se, 1, stats);
+        return RTX_OK;
+    }
+    if (stats) *stats = slot.stats;
     return RTX_OK;
 }
 

@@ -162,6 +162,53 @@ def test_cost_ordered_units_do_not_change_the_frame(rtx, synth):
         assert np.array_equal(other, other_ref)
 
 
+def test_frames_in_flight(big, rtx, synth):
+    """rtx_render_device_async / rtx_render_tiles_async / rtx_render_wait: two frames enqueued back to
+    back give the images and statistics of two rtx_render calls; a frame that needs host decisions
+    (several ray-tree levels) is rendered inside the async call; misuse is reported, not executed."""
+    import torch
+    _, ctx = big
+    w, h = 960, 540
+    ref, sr = ctx.render(w, h, 10, 10)
+    bufs = [torch.full((h * w * 3,), 9, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    with pytest.raises(rtx.RtxError):
+        ctx.render_wait()                                   # nothing in flight
+    ctx.render_device_async(w, h, 10, 10, bufs[0].data_ptr())
+    ctx.render_device_async(w, h, 10, 10, bufs[1].data_ptr())
+    with pytest.raises(rtx.RtxError):
+        ctx.render_device_async(w, h, 10, 10, bufs[0].data_ptr())   # a third frame has no slot
+    for b in bufs:
+        st = ctx.render_wait()
+        assert (st.primary_rays, st.shadow_rays, st.shaded_nodes, st.batches) == (sr.primary_rays, sr.shadow_rays, sr.shaded_nodes, 1)
+        assert st.closest_launches == 1 and st.shadow_launches == 1 and st.render_ms > 0
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert np.array_equal(b.cpu().numpy().reshape(h, w, 3), ref)
+    # tile slabs, two virtual ranks, both in flight
+    world = 2
+    tpr = rtx.tiles_per_rank(w, h, world)
+    slabs = torch.zeros(world * tpr * 192, dtype=torch.uint8, device="cuda:0")
+    img = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    for r in range(world):
+        ctx.render_tiles_async(w, h, 10, 10, r, world, slabs.data_ptr() + r * tpr * 192)
+    assert sum(ctx.render_wait().primary_rays for _ in range(world)) == w * h
+    ctx.assemble_tiles(w, h, world, slabs.data_ptr(), img.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy().reshape(h, w, 3), ref)
+    # a reflective scene has several levels: the async call renders it at once, wait returns its statistics
+    flat = synth.heightfield_scene(64, spec=0.3, glass_lattice=3)
+    with rtx.Context(0) as c2:
+        c2.set_scene(flat)
+        c2.build()
+        a, sa = c2.render(200, 120, 5, 10)
+        out = torch.zeros(120 * 200 * 3, dtype=torch.uint8, device="cuda:0")
+        c2.render_device_async(200, 120, 5, 10, out.data_ptr())
+        sb = c2.render_wait()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(120, 200, 3), a)
+        assert sb.traced_rays == sa.traced_rays and sb.closest_launches == sa.closest_launches
+
+
 def test_render_device_writes_the_same_row_major_frame(big):
     """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
     import torch
