@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5),
                     help="BASELINE configuration: 3 = 1M triangles at 1080p (default, the single-GPU bench workload), 4 = 16M triangles + "
                          "64 glass spheres at 4K depth 5, 5 = 62.72M triangles + 1.28M spheres at 8K depth 5")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="contexts (streams) the frames alternate between; 0 = 1 on a single GPU (per-kernel times stay those of a "
+                         "kernel running alone), 2 on two GPUs, 3 beyond (a rank's share of the frame cannot fill the GPU)")
     ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
@@ -103,22 +106,30 @@ def main():
         flat = rdist.broadcast_scene(flat, 0, cdev)
     bcast_ms = (time.time() - t_b0) * 1e3
 
-    ctx = rtx.Context(dev_index)
-    if args.no_cost_order:
-        ctx.set_option("cost_order", 0)
-    for i, v in enumerate([x for x in args.tune.split(",") if x]):
-        ctx.set_option("tune%d" % i, int(v))
-    ctx.set_scene(flat)
-    for i, v in enumerate([x for x in args.tune.split(",") if x]):
-        ctx.set_option("tune%d" % i, int(v))
-    build = ctx.build()
+    # One context = one HIP stream with its own workspace and copy of the scene. With two, the frames
+    # alternate between them, so the tail of one frame's kernels overlaps the start of the next frame's.
+    ctxs = []
+    n_contexts = args.contexts if args.contexts > 0 else (1 if world == 1 else 2 if world == 2 else 3)
+    for _ in range(n_contexts):
+        c = rtx.Context(dev_index)
+        if args.no_cost_order:
+            c.set_option("cost_order", 0)
+        for i, v in enumerate([x for x in args.tune.split(",") if x]):
+            c.set_option("tune%d" % i, int(v))
+        c.set_scene(flat)
+        for i, v in enumerate([x for x in args.tune.split(",") if x]):
+            c.set_option("tune%d" % i, int(v))
+        build = c.build()
+        ctxs.append(c)
+    ctx = ctxs[0]
     w, h = args.width, args.height
     tpr = rtx.tiles_per_rank(w, h, world)
     # Frames are pipelined: while the GPU renders frame k the host collects frame k - 1 (and, for
     # N > 1, its slabs travel while frame k renders and frame k - 2 is assembled). Every frame that
     # was enqueued inside the timed region is complete before the clock stops.
-    ring = 3
-    images = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    in_flight = max(1, len(ctxs))     # frames enqueued beyond the one being collected
+    ring = in_flight + 2
+    images = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
     slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
     gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
     gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
@@ -156,7 +167,7 @@ def main():
 
     def collect():
         """Collects the oldest frame in flight; for N > 1 sends its slab on its way."""
-        account(ctx.render_wait())
+        account(ctxs[state["collected"] % len(ctxs)].render_wait())
         idx = state["collected"] % ring
         state["collected"] += 1
         if world == 1:
@@ -174,10 +185,10 @@ def main():
         k = state["enqueued"]
         state["enqueued"] += 1
         if world == 1:   # single GPU: the frame is written row-major in place
-            ctx.render_device_async(w, h, args.depth, 10, images[k & 1].data_ptr())
+            ctxs[k % len(ctxs)].render_device_async(w, h, args.depth, 10, images[k % len(images)].data_ptr())
         else:
-            ctx.render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
-        if state["enqueued"] - state["collected"] > 1:
+            ctxs[k % len(ctxs)].render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
+        if state["enqueued"] - state["collected"] > in_flight:
             collect()
 
     def sync():
@@ -199,7 +210,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    image = images[(state["enqueued"] - 1) & 1] if world == 1 else image
+    image = images[(state["enqueued"] - 1) % len(images)] if world == 1 else image
     total_traced = acc["traced"]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -253,7 +264,8 @@ def main():
                                    "LBVH traversal, scene and BVH resident in HBM"
                                    % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth,
-                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if world > 1 else "single GPU"},
+                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if world > 1 else "single GPU",
+                       "frames_in_flight_per_gpu": len(ctxs) + 1},
             "rays_per_frame": total_traced / args.steps,
             "sharded_frame_equals_single_gpu_frame": sharded_equal,
             "device_frame_ms_rank0": acc["render_ms"] / args.steps,
@@ -274,7 +286,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, w, h, args.depth, 10, args.cpu_stride)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
