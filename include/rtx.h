@@ -149,7 +149,10 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^22)
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
- *   "tune2"         traversal workgroups per CU (1..8, default 4)
+ *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
+ *                   launches (default 24 = 6 units), byte 1 for shadow launches (default 10 = 2.5 units); small
+ *                   launches get fewer workgroups per CU accordingly
+ *   "tune2"         most traversal workgroups per CU (1..8, default 4)
  *   "tune3"         primitives per leaf (1..8, default 1; at the next rtx_build)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.

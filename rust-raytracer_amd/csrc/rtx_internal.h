@@ -87,7 +87,7 @@ struct DevScene {
     int* spill;                 // [spill_entries][spill_stride] overflow of the per-lane traversal stacks
     uint32_t spill_stride;      // thread slots = largest traversal grid * 256
     uint32_t spill_entries;
-    int32_t tune[4];            // traversal tuning: [0] busy lanes below which a wavefront shares work, [2] workgroups per CU, [3] leaf size
+    int32_t tune[4];            // traversal tuning: [0] busy lanes below which a wavefront shares work, [1] work units a wavefront should expect, in quarters (byte 0 closest hit, byte 1 shadow), [2] most workgroups per CU, [3] leaf size
     unsigned long long* stamps; // diagnostics: [2 kinds][spill_stride / 64 wavefronts][4], or nullptr
 };
 
@@ -136,7 +136,8 @@ struct rtx_context {
     int64_t opt_batch_pixels = 1 << 22;
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     uint32_t num_cus = 256;
-    int32_t opt_tune[4] = {48, 8, 4, RTX_LEAF_MAX};
+    int32_t opt_tune[4] = {48, 24 + (10 << 8), 4, RTX_LEAF_MAX};
+    float hit_fraction = 1.0f;   // share of the last frame's closest-hit rays that hit something
     int64_t opt_stamps = 0;
 
     // Frames in flight (rtx_render_*_async / rtx_render_wait): a frame whose kernels need no host

@@ -983,6 +983,12 @@ struct EventPool {
     }
 };
 
+// Remembers which share of a frame's closest-hit rays hit something (sizes the next shadow launch).
+void note_hit_fraction(rtx_context* ctx, const Ctl& hc, uint64_t primary) {
+    const double closest = (double)primary + (double)hc.stat[ST_REFLECT] + (double)hc.stat[ST_REFRACT] - (double)hc.stat[ST_SKIPPED];
+    if (closest >= 1.0) ctx->hit_fraction = (float)std::min(1.0, std::max(1.0 / 256.0, (double)hc.stat[ST_NODES] / closest));
+}
+
 // Counters and event times of a finished frame.
 void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
                 const std::vector<std::pair<hipEvent_t, hipEvent_t>>& closest_events,
@@ -1015,15 +1021,22 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
     *stats = rs;
 }
 
-// Every traversal launch is bounded by the spill area: at most blocks_per_cu * CUs workgroups.
-uint32_t trav_blocks(const rtx_context* ctx, uint64_t items) {
-    const uint64_t cap = (uint64_t)ctx->num_cus * (uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8);
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items + RTX_BLOCK - 1) / RTX_BLOCK, cap));
+// Workgroups of a traversal launch. A launch is bounded by the spill area (at most tune[2] * CUs
+// workgroups) and sized so that a wavefront expects `quarter_units / 4` work units: a launch with
+// few units runs faster on fewer wavefronts (every step of a ray waits less for the CU's address
+// unit and caches, and the expensive-first unit order needs more than one unit per wavefront).
+uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units) {
+    const uint32_t max_per_cu = (uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8);
+    const double waves = expected_items / 64.0 * 4.0 / (double)std::max<uint32_t>(quarter_units, 1);
+    const double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
+    const uint32_t wgs_per_cu = (uint32_t)std::min<double>(std::max<double>(per_cu, 1.0), (double)max_per_cu);
+    const uint64_t cap = (uint64_t)ctx->num_cus * wgs_per_cu;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items_upper + RTX_BLOCK - 1) / RTX_BLOCK, cap));
 }
 // shade: the hits will be shaded, so they are counted per chunk and the node slots laid out (k_scan_chunks).
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st) {
-    hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper)), dim3(RTX_BLOCK), 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo,
+    hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), dim3(RTX_BLOCK), 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo,
                        shade ? wk.chunk_cnt : nullptr);
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
@@ -1031,7 +1044,8 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
                    UnitOrder* uo, hipStream_t st) {
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
-    const dim3 grid(trav_blocks(ctx, tasks_upper)), block(RTX_BLOCK);
+    // the share of rays that hit something is not known before the launch: the last frame's share stands in
+    const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu)), block(RTX_BLOCK);
     if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
     else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
     else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
@@ -1225,6 +1239,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         std::memset(host_ctl, 0, sizeof(Ctl));
     }
     RTX_HIP(ctx, hipGetLastError());
+    note_hit_fraction(ctx, *host_ctl, primary);
     if (stats) fill_stats(*host_ctl, primary, f0, f1, closest_events, shadow_events, n_batches, stats);
     return RTX_OK;
 }
@@ -1266,6 +1281,7 @@ int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats) {
         const Ctl* hc = (const Ctl*)((char*)ctx->pinned + (size_t)(2 + idx) * 4096);
         if (hc->overflow)   // rare: the frame's ray tree outgrew the queues; render it again the patient way
             return rtx_render_impl(ctx, slot.w, slot.h, slot.depth, slot.samples, slot.rank, slot.world, slot.out, stats, slot.direct);
+        note_hit_fraction(ctx, *hc, slot.primary);
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ce{{slot.a, slot.b}}, se;
         if (slot.has_shadow) se.emplace_back(slot.c, slot.d);
         if (stats) fill_stats(*hc, slot.primary, slot.f0, slot.f1, ce, se, 1, stats);
