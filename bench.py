@@ -64,7 +64,7 @@ def main():
                          "64 glass spheres at 4K depth 5, 5 = 62.72M triangles + 1.28M spheres at 8K depth 5")
     ap.add_argument("--contexts", type=int, default=0,
                     help="contexts (streams) the frames alternate between; 0 = 1 on a single GPU (per-kernel times stay those of a "
-                         "kernel running alone), 2 on two GPUs, 3 beyond (a rank's share of the frame cannot fill the GPU)")
+                         "kernel running alone), 3 on several GPUs (a rank's share of the frame cannot fill the GPU)")
     ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
@@ -109,7 +109,7 @@ def main():
     # One context = one HIP stream with its own workspace and copy of the scene. With two, the frames
     # alternate between them, so the tail of one frame's kernels overlaps the start of the next frame's.
     ctxs = []
-    n_contexts = args.contexts if args.contexts > 0 else (1 if world == 1 else 2 if world == 2 else 3)
+    n_contexts = args.contexts if args.contexts > 0 else (1 if world == 1 else 3)
     for _ in range(n_contexts):
         c = rtx.Context(dev_index)
         if args.no_cost_order:
