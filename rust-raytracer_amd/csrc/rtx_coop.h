@@ -142,8 +142,8 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
             const float dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
             const float i0 = __shfl(rb.inv.x, src), i1 = __shfl(rb.inv.y, src), i2 = __shfl(rb.inv.z, src);
-            const float m0 = __shfl(rb.oim.x, src), m1 = __shfl(rb.oim.y, src), m2 = __shfl(rb.oim.z, src);
-            const float p0 = __shfl(rb.oip.x, src), p1 = __shfl(rb.oip.y, src), p2 = __shfl(rb.oip.z, src);
+            const float m0 = __shfl(rb.on.x, src), m1 = __shfl(rb.on.y, src), m2 = __shfl(rb.on.z, src);
+            const float p0 = __shfl(rb.of.x, src), p1 = __shfl(rb.of.y, src), p2 = __shfl(rb.of.z, src);
             const float tl = ANY ? __shfl(t_limit, src) : 0.0f, dl = ANY ? __shfl(dist_light, src) : 0.0f;
             if (giver) ++bot;
             if (taker) {
@@ -152,8 +152,8 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                 o = v3(ox, oy, oz);
                 d = v3(dx, dy, dz);
                 rb.inv = v3(i0, i1, i2);
-                rb.oim = v3(m0, m1, m2);
-                rb.oip = v3(p0, p1, p2);
+                rb.on = v3(m0, m1, m2);
+                rb.of = v3(p0, p1, p2);
                 if (ANY) {
                     t_limit = tl;
                     dist_light = dl;

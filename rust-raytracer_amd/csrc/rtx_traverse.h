@@ -60,31 +60,25 @@ RTX_D void trace_exhaustive(const DevScene& s, V3 o, V3 d, float& best_t, int& b
 // from the unfused one by a rounding of the box coordinate, far inside the padding;
 // only box tests are fused, primitive tests keep the reference's operation order.
 struct RayBox {
-    V3 oim, oip;   // (o + pad) * inv, (o - pad) * inv
+    V3 on, of;   // offsets of the near and far planes: (o +- pad) * inv with the sign that widens the box
     V3 inv;
 };
 RTX_D float safe_inv(float d) {
     return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d;
 }
+// The plane of a box a ray enters first is its low one where the direction is positive and
+// its high one where it is negative, so near and far are picked by sign, not by min / max:
+// with low <= high and pad >= 0 both give the same numbers (rounding is monotone).
 RTX_D RayBox make_raybox(const DevScene& s, V3 o, V3 d) {
     const float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
     const float pad = s.pad_rel * m;
     RayBox rb;
     rb.inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    rb.oim = v3((o.x + pad) * rb.inv.x, (o.y + pad) * rb.inv.y, (o.z + pad) * rb.inv.z);
-    rb.oip = v3((o.x - pad) * rb.inv.x, (o.y - pad) * rb.inv.y, (o.z - pad) * rb.inv.z);
+    const V3 om = v3((o.x + pad) * rb.inv.x, (o.y + pad) * rb.inv.y, (o.z + pad) * rb.inv.z);   // goes with a box's low planes
+    const V3 op = v3((o.x - pad) * rb.inv.x, (o.y - pad) * rb.inv.y, (o.z - pad) * rb.inv.z);   // goes with its high planes
+    rb.on = v3(rb.inv.x < 0.0f ? op.x : om.x, rb.inv.y < 0.0f ? op.y : om.y, rb.inv.z < 0.0f ? op.z : om.z);
+    rb.of = v3(rb.inv.x < 0.0f ? om.x : op.x, rb.inv.y < 0.0f ? om.y : op.y, rb.inv.z < 0.0f ? om.z : op.z);
     return rb;
-}
-// Conservative slab test; t_in is the entry parameter (can be negative).
-RTX_D bool box_hit(const RayBox& rb, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
-                   float best_t, float& t_in) {
-    const float ax = __builtin_fmaf(bx0, rb.inv.x, -rb.oim.x), bx = __builtin_fmaf(bx1, rb.inv.x, -rb.oip.x);
-    const float ay = __builtin_fmaf(by0, rb.inv.y, -rb.oim.y), by = __builtin_fmaf(by1, rb.inv.y, -rb.oip.y);
-    const float az = __builtin_fmaf(bz0, rb.inv.z, -rb.oim.z), bz = __builtin_fmaf(bz1, rb.inv.z, -rb.oip.z);
-    const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    t_in = lo;
-    return (lo <= hi) && (hi >= 0.0f) && (lo <= best_t);
 }
 
 // Diagnostics: one record per wavefront slot of a traversal launch (see rtx_debug_stamps).
@@ -182,18 +176,18 @@ struct TravStack {
 #endif
 constexpr float kSphereK = RTX_SPHERE_K;
 
+// wn* / wf*: the four children's near and far plane bytes of one axis; ln* / lf*: the matching offsets.
 template <bool WIDEN>
-RTX_D void node4_slabs(const uint4& B, const uint4& C, uint32_t nchild, const RayBox& rb, float limit, float sx, float sy,
-                       float sz, float lx, float ly, float lz, float hx, float hy, float hz, const float* e, float* t) {
+RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, uint32_t wfy, uint32_t wfz, uint32_t nchild,
+                       const RayBox& rb, float limit, float sx, float sy, float sz, float lnx, float lny, float lnz, float lfx,
+                       float lfy, float lfz, const float* e, float* t) {
     const float inf = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int sh = 8 * k;
-        const float ax = __builtin_fmaf((float)((B.x >> sh) & 0xffu), sx, lx), bx = __builtin_fmaf((float)((B.w >> sh) & 0xffu), sx, hx);
-        const float ay = __builtin_fmaf((float)((B.y >> sh) & 0xffu), sy, ly), by = __builtin_fmaf((float)((C.x >> sh) & 0xffu), sy, hy);
-        const float az = __builtin_fmaf((float)((B.z >> sh) & 0xffu), sz, lz), bz = __builtin_fmaf((float)((C.y >> sh) & 0xffu), sz, hz);
-        float nx = fminf(ax, bx), ny = fminf(ay, by), nz = fminf(az, bz);
-        float fx = fmaxf(ax, bx), fy = fmaxf(ay, by), fz = fmaxf(az, bz);
+        float nx = __builtin_fmaf((float)((wnx >> sh) & 0xffu), sx, lnx), fx = __builtin_fmaf((float)((wfx >> sh) & 0xffu), sx, lfx);
+        float ny = __builtin_fmaf((float)((wny >> sh) & 0xffu), sy, lny), fy = __builtin_fmaf((float)((wfy >> sh) & 0xffu), sy, lfy);
+        float nz = __builtin_fmaf((float)((wnz >> sh) & 0xffu), sz, lnz), fz = __builtin_fmaf((float)((wfz >> sh) & 0xffu), sz, lfz);
         if (WIDEN) {   // planes move outward by e: e * |1/d| in ray parameter
             const float wx = e[k] * fabsf(rb.inv.x), wy = e[k] * fabsf(rb.inv.y), wz = e[k] * fabsf(rb.inv.z);
             nx -= wx; ny -= wy; nz -= wz;
@@ -228,9 +222,14 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
     const float sx = stx * rb.inv.x, sy = sty * rb.inv.y, sz = stz * rb.inv.z;
     const uint32_t nchild = (meta >> 24) & 7u;
     const float ox = u2f(A.x), oy = u2f(A.y), oz = u2f(A.z);
-    const float lx = __builtin_fmaf(ox, rb.inv.x, -rb.oim.x), hx = __builtin_fmaf(ox, rb.inv.x, -rb.oip.x);
-    const float ly = __builtin_fmaf(oy, rb.inv.y, -rb.oim.y), hy = __builtin_fmaf(oy, rb.inv.y, -rb.oip.y);
-    const float lz = __builtin_fmaf(oz, rb.inv.z, -rb.oim.z), hz = __builtin_fmaf(oz, rb.inv.z, -rb.oip.z);
+    const float lnx = __builtin_fmaf(ox, rb.inv.x, -rb.on.x), lfx = __builtin_fmaf(ox, rb.inv.x, -rb.of.x);
+    const float lny = __builtin_fmaf(oy, rb.inv.y, -rb.on.y), lfy = __builtin_fmaf(oy, rb.inv.y, -rb.of.y);
+    const float lnz = __builtin_fmaf(oz, rb.inv.z, -rb.on.z), lfz = __builtin_fmaf(oz, rb.inv.z, -rb.of.z);
+    // low-plane bytes: B.x B.y B.z, high-plane bytes: B.w C.x C.y
+    const bool ngx = rb.inv.x < 0.0f, ngy = rb.inv.y < 0.0f, ngz = rb.inv.z < 0.0f;
+    const uint32_t wnx = ngx ? B.w : B.x, wfx = ngx ? B.x : B.w;
+    const uint32_t wny = ngy ? C.x : B.y, wfy = ngy ? B.y : C.x;
+    const uint32_t wnz = ngz ? C.y : B.z, wfz = ngz ? B.z : C.y;
     const float inf = __builtin_inff();
     float t[4];
     int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
@@ -250,9 +249,9 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
             const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
             e[k] = kd2 * __builtin_amdgcn_rcpf(den) * ((hbits != 0x7c00u) ? 1.002f : 0.0f);
         }
-        node4_slabs<true>(B, C, nchild, rb, limit, sx, sy, sz, lx, ly, lz, hx, hy, hz, e, t);
+        node4_slabs<true>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, e, t);
     } else {
-        node4_slabs<false>(B, C, nchild, rb, limit, sx, sy, sz, lx, ly, lz, hx, hy, hz, nullptr, t);
+        node4_slabs<false>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, nullptr, t);
     }
 #define RTX_CE(i, j)                                   \
     do {                                               \
