@@ -247,6 +247,23 @@ def main():
                     traffic = json.load(f)["kernels"]["shadow" if kname.startswith("k_shadow") else "closest"]["bytes_per_launch"]
             except Exception:
                 traffic = None
+        # device-to-device copy rate of this GPU (read + write bytes), outside the timed region: the practical HBM ceiling
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "Mrays/sec (primary+shadow+secondary) per GPU and per node; frame time",
             "value": total_traced / elapsed / 1e6,
@@ -278,6 +295,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray,
                          "measured_hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         "device_copy_GBps": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "note": "achieved = algorithmic bytes (binary-BVH figure: ray in + 2*ceil(log2 N) boxes + one primitive + "
                                  "hit out per ray) / launch time; L2 and the Infinity Cache serve most node fetches, so the HBM "
                                  "traffic measured with PMC counters (traffic) is far below it and frac can exceed 1: the kernel is "
