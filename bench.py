@@ -66,6 +66,7 @@ def main():
                     help="contexts (streams) the frames alternate between; 0 = 1 on a single GPU (per-kernel times stay those of a "
                          "kernel running alone), 3 on several GPUs (a rank's share of the frame cannot fill the GPU)")
     ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
+    ap.add_argument("--batch-pixels", type=int, default=0, help="pixels per wavefront batch (0 = the library's default)")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
     small_spheres = 0
@@ -114,6 +115,8 @@ def main():
         c = rtx.Context(dev_index)
         if args.no_cost_order:
             c.set_option("cost_order", 0)
+        if args.batch_pixels > 0:
+            c.set_option("batch_pixels", args.batch_pixels)
         for i, v in enumerate([x for x in args.tune.split(",") if x]):
             c.set_option("tune%d" % i, int(v))
         c.set_scene(flat)

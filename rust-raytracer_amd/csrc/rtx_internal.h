@@ -133,7 +133,7 @@ struct rtx_context {
 
     // knobs (rtx_set_option)
     int64_t opt_force_mode = 0;   // 0 auto, 1 exhaustive, 2 bvh
-    int64_t opt_batch_pixels = 1 << 22;
+    int64_t opt_batch_pixels = 1 << 24;
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     uint32_t num_cus = 256;
     int32_t opt_tune[4] = {48, 24 + (10 << 8), 4, RTX_LEAF_MAX};
