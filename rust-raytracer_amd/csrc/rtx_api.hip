@@ -95,6 +95,8 @@ void rtx_destroy(rtx_context* ctx) {
     for (auto& e : ctx->order_bufs) (void)hipFree(e.second);
     ctx->order_bufs.clear();
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    for (auto& slot : ctx->async_slots)
+        for (hipEvent_t e : slot.events) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

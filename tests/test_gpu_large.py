@@ -209,6 +209,28 @@ def test_frames_in_flight(big, rtx, synth):
         assert sb.traced_rays == sa.traced_rays and sb.closest_launches == sa.closest_launches
 
 
+def test_launch_sizing_does_not_change_the_frame(big):
+    """Traversal grids are sized from the work units a wavefront should expect (tune1) and a cap of
+    workgroups per CU (tune2), the shadow launch also from the last frame's hit share. Frames of
+    several sizes, in an order that makes the remembered share wrong, equal the frames of the
+    largest grid; so do frames with one workgroup per CU and with one unit per wavefront."""
+    _, ctx = big
+    sizes = ((1920, 1080), (96, 64), (680, 384), (1920, 1080))
+    ctx.set_option("tune1", 1 + (1 << 8))      # a quarter unit per wavefront: every launch takes the largest grid
+    refs = [ctx.render(w, h, 10, 10) for w, h in sizes]
+    try:
+        for t1, t2 in ((24 + (10 << 8), 4), (255 + (255 << 8), 4), (24 + (10 << 8), 1), (4 + (4 << 8), 8)):
+            ctx.set_option("tune1", t1)
+            ctx.set_option("tune2", t2)
+            for (w, h), (ref, sr) in zip(sizes, refs):
+                img, st = ctx.render(w, h, 10, 10)
+                assert np.array_equal(img, ref), (t1, t2, w, h)
+                assert (st.shadow_rays, st.shaded_nodes) == (sr.shadow_rays, sr.shaded_nodes)
+    finally:
+        ctx.set_option("tune1", 24 + (10 << 8))
+        ctx.set_option("tune2", 4)
+
+
 def test_render_device_writes_the_same_row_major_frame(big):
     """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
     import torch
