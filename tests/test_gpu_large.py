@@ -340,3 +340,64 @@ def test_errors_before_scene_and_build(rtx):
         assert e.value.status == 6      # RTX_ERR_UNSUPPORTED
         rgb, _ = ctx.render(8, 8, depth=0)
         assert not rgb.any()            # depth 0: every pixel black (src/lib.rs:203-205)
+
+
+def _mirror_box(rtx):
+    """A closed box of 12 mirror triangles (plus more so that the BVH is used) with the camera and
+    a light inside: every ray hits, so a pixel's ray tree has exactly `depth` shaded nodes."""
+    f = rtx.FlatScene()
+    c = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32)
+    quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+    tris = []
+    for a, b, cc, d in quads:
+        tris += [[c[a], c[b], c[cc]], [c[a], c[cc], c[d]]]
+    # small clutter inside the box so that there are more than 16 primitives
+    rng = np.random.default_rng(3)
+    for _ in range(24):
+        p = rng.uniform(-0.8, 0.8, 3).astype(np.float32)
+        tris.append([p, p + rng.uniform(-0.1, 0.1, 3).astype(np.float32), p + rng.uniform(-0.1, 0.1, 3).astype(np.float32)])
+    f.tri_pos = np.asarray(tris, np.float32)
+    m = f.add_material((0.6, 0.5, 0.4), (0.1, 0.1, 0.1), (0.5, 0.5, 0.5), 0.3, 0.0)
+    f.tri_mat = np.full((len(tris), 3), rtx.MATERIAL_NONE, np.uint32)
+    f.tri_mat[:, 0] = m
+    f.tri_flags = np.zeros((len(tris),), np.uint8)
+    f.add_light(rtx.LIGHT_POINT, (0.2, 0.5, 0.1), (1, 1, 1))
+    f.set_camera((0.0, 0.0, 0.9), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 0.9)
+    return f
+
+
+def test_ray_tree_larger_than_the_node_pool_is_rendered_in_smaller_batches(rtx, orc):
+    """With pool_factor 1 the node pool holds one node per batch pixel, the mirror box needs `depth`
+    per pixel: the batch overflows and is rendered again in halves until it fits. Image, ray counts
+    and node counts must be those of a frame that never overflowed, and of the oracle."""
+    import torch
+    flat = _mirror_box(rtx)
+    w, h, depth = 128, 64, 6
+    ref = orc.OracleScene.from_flat(flat).render(w, h, depth, 10, threads=8)
+    with rtx.Context(0) as ctx:
+        ctx.set_option("pool_factor", 16)
+        ctx.set_scene(flat)
+        ctx.build()
+        assert ctx.build_stats["uses_bvh"] == 1
+        big, sb = ctx.render(w, h, depth, 10)
+        assert sb.batches == 1 and sb.shaded_nodes == depth * w * h
+    with rtx.Context(0) as ctx:
+        ctx.set_option("pool_factor", 1)
+        ctx.set_scene(flat)
+        ctx.build()
+        small, ss = ctx.render(w, h, depth, 10)
+        assert ss.batches >= 8                       # 6 nodes per pixel need batches of at most 1/8 of the pool's pixels
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_device_async(w, h, depth, 10, out.data_ptr())
+        sa = ctx.render_wait()
+        torch.cuda.synchronize()
+    assert np.array_equal(small, big)
+    assert np.array_equal(out.cpu().numpy().reshape(h, w, 3), big)
+    for st in (ss, sa):
+        assert (st.primary_rays, st.shadow_rays, st.reflect_rays, st.refract_rays, st.skipped_rays, st.shaded_nodes) == \
+            (sb.primary_rays, sb.shadow_rays, sb.reflect_rays, sb.refract_rays, sb.skipped_rays, sb.shaded_nodes)
+    rs = ref["stats"]
+    assert (sb.shadow_rays, sb.reflect_rays, sb.skipped_rays, sb.shaded_nodes) == \
+        (rs["shadow_rays"], rs["reflect_rays"], rs["last_level_rays"], rs["shaded_nodes"])
+    diff = np.abs(big.astype(int) - ref["rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
