@@ -148,6 +148,8 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "force_mode"   0 = automatic, 1 = exhaustive kernel, 2 = BVH (takes effect at the next rtx_build)
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^24; the workspace is sized by min(this, pixels of the frame))
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
+ *   "kernel_timing" 1 (default): the traversal launches carry timing events (closest_ms, shadow_ms of the statistics);
+ *                   0: no events, a frame's launches follow each other a few microseconds closer
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
  *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
  *                   launches (default 24 = 6 units), byte 1 for shadow launches (default 10 = 2.5 units); small

@@ -126,6 +126,8 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
+    } else if (k == "kernel_timing") {
+        ctx->opt_kernel_timing = value ? 1 : 0;
     } else if (k == "cost_order") {
         ctx->opt_cost_order = value ? 1 : 0;
     } else if (k == "stamps") {

@@ -157,6 +157,7 @@ struct rtx_context {
     };
     AsyncSlot async_slots[2];
     uint32_t async_head = 0, async_count = 0;     // oldest slot, frames waiting
+    int64_t opt_kernel_timing = 1;   // events on the traversal launches (closest_ms / shadow_ms of the statistics)
     int64_t opt_cost_order = 1;   // level-0 traversal launches hand out their units most expensive first (costs of the previous frame)
     std::vector<std::pair<uint64_t, void*>> order_bufs;   // (kind, batch, capacity) -> UnitOrder
 };

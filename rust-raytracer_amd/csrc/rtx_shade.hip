@@ -17,6 +17,8 @@
 #include <cstring>
 #include <utility>
 
+#include <hip/hip_ext.h>
+
 #include "rtx_coop.h"
 #include "rtx_shading.h"
 
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
     __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
-    if (sort_uo && blockIdx.x == gridDim.x - 1) order_units(sort_uo);   // costs of the closest-hit launch just finished
+    if (sort_uo && blockIdx.x == 0) order_units(sort_uo);   // costs of the closest-hit launch just finished
     if (block_sees_overflow(ctl)) return;
     const uint32_t n = ctl->n_rays[qi];
     const uint32_t pool_base = ctl->pool_base;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples,
                                                        OutMap out, int finalize, UnitOrder* sort_uo) {
     Ctl* ctl = wk.ctl;
-    if (sort_uo && blockIdx.x == gridDim.x - 1) order_units(sort_uo);   // costs of the shadow launch just finished
+    if (sort_uo && blockIdx.x == 0) order_units(sort_uo);   // costs of the shadow launch just finished
     if (block_sees_overflow(ctl)) return;
     const uint32_t nn = ctl->n_nodes;
     if (finalize && blockIdx.x == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
@@ -1008,7 +1010,7 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
         float total = 0.0f;
         for (auto& p : evs) {
             float e = 0.0f;
-            (void)hipEventElapsedTime(&e, p.first, p.second);
+            if (p.first && p.second) (void)hipEventElapsedTime(&e, p.first, p.second);   // null: kernel timing is off
             total += e;
         }
         return total;
@@ -1034,22 +1036,24 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items_upper + RTX_BLOCK - 1) / RTX_BLOCK, cap));
 }
 // shade: the hits will be shaded, so they are counted per chunk and the node slots laid out (k_scan_chunks).
+// t0 / t1 (optional) take the traversal kernel's own start and end times: events attached to the
+// launch, because events recorded between launches each cost the stream several idle microseconds.
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
-                    bool shade, hipStream_t st) {
-    hipLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), dim3(RTX_BLOCK), 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo,
-                       shade ? wk.chunk_cnt : nullptr);
+                    bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+    hipExtLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), dim3(RTX_BLOCK), 0, st,
+                          t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, shade ? wk.chunk_cnt : nullptr);
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
-                   UnitOrder* uo, hipStream_t st) {
+                   UnitOrder* uo, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
     const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu)), block(RTX_BLOCK);
-    if (any && area) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-    else if (any) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-    else if (area) hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, s, wk, depth, n_slots, uo);
-    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, s, wk, depth, n_slots, uo);
+    if (any && area) hipExtLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+    else if (any) hipExtLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+    else if (area) hipExtLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+    else hipExtLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
 }
 
 // The cost / order buffer of one (kind, batch) pair of level-0 launches; nullptr when the
@@ -1162,26 +1166,23 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         for (uint32_t level = 0; level < levels; ++level) {
             hipEvent_t a = ev.next(), b = ev.next();
             if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
-            RTX_HIP(ctx, hipEventRecord(a, st));
             const PrimaryGen& pg = (level == 0) ? gen : no_gen;
             // level-0 launches of unchanged size reuse the unit costs of the previous frame (see UnitOrder)
             const bool ordered = level == 0 && cur_batch == batch;
             UnitOrder* uo0 = ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr;
             UnitOrder* uo1 = nullptr;
-            launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st);
-            RTX_HIP(ctx, hipEventRecord(b, st));
-            closest_events.emplace_back(a, b);
+            const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
+            launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, no_kt ? nullptr : a, no_kt ? nullptr : b);
+            closest_events.emplace_back(no_kt ? nullptr : a, no_kt ? nullptr : b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
                                PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = ev.next(), d = ev.next();
                 if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
-                RTX_HIP(ctx, hipEventRecord(c, st));
                 const uint64_t tasks = (uint64_t)n_rays * n_slots;
                 uo1 = ordered ? unit_order(ctx, 1, n_batches - 1, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup) : nullptr;
-                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st);
-                RTX_HIP(ctx, hipEventRecord(d, st));
-                shadow_events.emplace_back(c, d);
+                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st, no_kt ? nullptr : c, no_kt ? nullptr : d);
+                shadow_events.emplace_back(no_kt ? nullptr : c, no_kt ? nullptr : d);
             }
             hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
                                out_map, single_level ? 1 : 0, uo1);

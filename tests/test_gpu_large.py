@@ -231,6 +231,22 @@ def test_launch_sizing_does_not_change_the_frame(big):
         ctx.set_option("tune2", 4)
 
 
+def test_kernel_timing_option(big):
+    """kernel_timing 0 drops the events on the traversal launches: same frame and counts,
+    closest_ms / shadow_ms are reported as 0, the launch counts stay."""
+    _, ctx = big
+    ref, sr = ctx.render(640, 360, 10, 10)
+    assert sr.closest_ms > 0 and sr.shadow_ms > 0 and sr.closest_ms + sr.shadow_ms <= sr.render_ms
+    ctx.set_option("kernel_timing", 0)
+    try:
+        img, st = ctx.render(640, 360, 10, 10)
+    finally:
+        ctx.set_option("kernel_timing", 1)
+    assert np.array_equal(img, ref)
+    assert (st.closest_ms, st.shadow_ms) == (0.0, 0.0) and st.render_ms > 0
+    assert (st.closest_launches, st.shadow_launches, st.shadow_rays) == (sr.closest_launches, sr.shadow_launches, sr.shadow_rays)
+
+
 def test_render_device_writes_the_same_row_major_frame(big):
     """rtx_render_device (image stays in HBM) against rtx_render (image copied to the host)."""
     import torch
