@@ -22,6 +22,20 @@
 #pragma once
 #include "rtx_traverse.h"
 
+#ifdef RTX_DIAG
+// Diagnostic build: lane occupancy of the traversal loop, summed over all wavefronts (index 0: closest hit, 1: any-hit).
+// [0] phase-1 iterations, [1] lanes with work in them, [2] of those on inner nodes, [3] iterations with both kinds,
+// [4] phase-2 iterations, [5] lanes with work in them, [6] of those on inner nodes, [7] iterations with both kinds,
+// [8] donation rounds, [9] queries (wavefront calls), [10] subtrees given
+// [12..16] queries by phase-2 length (0, 1-4, 5-16, 17-64, more), [17..21] phase-2 iterations in those classes
+static __device__ unsigned long long g_diag[2][32];
+#define RTX_DIAG_ADD(k, v) do { dg[k] += (uint32_t)(v); } while (0)
+#define RTX_DIAG_FLUSH() do { if ((threadIdx.x & 63) == 0) { const int c_ = dg[4] == 0 ? 0 : dg[4] <= 4 ? 1 : dg[4] <= 16 ? 2 : dg[4] <= 64 ? 3 : 4; dg[12 + c_] = 1; dg[17 + c_] = dg[4]; for (int k_ = 0; k_ < 22; ++k_) if (dg[k_]) atomicAdd(&g_diag[ANY ? 1 : 0][k_], (unsigned long long)dg[k_]); } } while (0)
+#else
+#define RTX_DIAG_ADD(k, v) do { } while (0)
+#define RTX_DIAG_FLUSH() do { } while (0)
+#endif
+
 struct CoopLds {
     unsigned long long slot[RTX_BLOCK];   // per lane's ray: closest: (t bits << 32) | id; any-hit: 0 = occluded, 1 = not
     int pair[RTX_BLOCK];                  // per wavefront: donor lane by rank
@@ -60,6 +74,10 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
         if (len > 0.0f) t_limit = ((dist_light + 4e-6f * m) / len) * 1.0001f + 1e-6f;
     }
     RayBox rb = make_raybox(s, o, d);
+#ifdef RTX_DIAG
+    uint32_t dg[22] = {};
+#endif
+    RTX_DIAG_ADD(9, 1);
 
     // ---- phase 1: one ray per lane ----
     uint64_t busy;
@@ -69,6 +87,12 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
     for (;;) {
         busy = __ballot(cur != kRefDone);
         if (busy == 0 || __popcll(busy) < threshold) break;
+#ifdef RTX_DIAG
+        {
+            const uint64_t nodes = __ballot(cur != kRefDone && cur >= 0), leaves = __ballot(cur < 0);
+            RTX_DIAG_ADD(0, 1); RTX_DIAG_ADD(1, __popcll(busy)); RTX_DIAG_ADD(2, __popcll(nodes)); RTX_DIAG_ADD(3, (nodes && leaves) ? 1 : 0);
+        }
+#endif
 #ifdef RTX_COUNT_STEPS
         const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
@@ -107,6 +131,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
     }
 #endif
     if (busy == 0) {   // wave-uniform
+        RTX_DIAG_FLUSH();
         out_t = best_t;
         out_id = ANY ? best_id : (best_id == 0x7fffffff ? -1 : best_id);
         return;
@@ -129,6 +154,13 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
         if (busy == 0) break;
         const bool can_give = has && sp > bot;
         const uint64_t don = __ballot(can_give);
+#ifdef RTX_DIAG
+        {
+            const uint64_t nodes = __ballot(has && cur >= 0), leaves = __ballot(cur < 0);
+            RTX_DIAG_ADD(4, 1); RTX_DIAG_ADD(5, __popcll(busy)); RTX_DIAG_ADD(6, __popcll(nodes)); RTX_DIAG_ADD(7, (nodes && leaves) ? 1 : 0);
+            if (~busy != 0 && don != 0) { RTX_DIAG_ADD(8, 1); RTX_DIAG_ADD(10, min(__popcll(~busy), __popcll(don))); }
+        }
+#endif
         if (~busy != 0 && don != 0) {   // wave-uniform
             const int np = min(__popcll(~busy), __popcll(don));
             const int rd = __popcll(don & lt), ri = __popcll(~busy & lt);
@@ -211,6 +243,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             }
         }
     }
+    RTX_DIAG_FLUSH();
     const unsigned long long key = __hip_atomic_load(&slot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (ANY) {
         out_t = 0.0f;

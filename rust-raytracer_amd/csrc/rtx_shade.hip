@@ -1325,3 +1325,12 @@ int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, 
     RTX_HIP(ctx, hipGetLastError());
     return RTX_OK;
 }
+
+#ifdef RTX_DIAG
+// Diagnostic build: reads and clears the lane-occupancy counters of rtx_coop.h (2 x 32 values: closest, any-hit).
+extern "C" int rtx_diag_counters(unsigned long long* out) {
+    unsigned long long zero[2][32] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
