@@ -86,7 +86,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
 #else
     for (;;) {
         busy = __ballot(cur != kRefDone);
-        if (busy == 0 || __popcll(busy) < threshold) break;
+        if (busy == 0 || (int)__popcll(busy) < threshold) break;
 #ifdef RTX_DIAG
         {
             const uint64_t nodes = __ballot(cur != kRefDone && cur >= 0), leaves = __ballot(cur < 0);
