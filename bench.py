@@ -67,6 +67,9 @@ def main():
                          "kernel running alone), 3 on several GPUs (a rank's share of the frame cannot fill the GPU)")
     ap.add_argument("--no-cost-order", action="store_true", help="hand out traversal work units in index order (experiments)")
     ap.add_argument("--batch-pixels", type=int, default=0, help="pixels per wavefront batch (0 = the library's default)")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="with one process: run the multi-GPU code path (process group of one rank, tile slab, all-gather, "
+                         "assembly) instead of the single-GPU one; for checking that path on a one-GPU box")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
     small_spheres = 0
@@ -83,15 +86,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    gloo = world > 1 and args.backend == "gloo"
+    multi = world > 1 or args.rehearse_dist        # the sharded code path (also with a single rank when rehearsing)
+    gloo = multi and args.backend == "gloo"
     dev_index = local_rank % torch.cuda.device_count() if gloo else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     cdev = torch.device("cpu") if gloo else dev       # where collective buffers live
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -103,14 +108,14 @@ def main():
 
     flat = synth.heightfield_scene(args.grid, spec=args.spec, glass_lattice=args.glass, small_spheres=small_spheres) if rank == 0 else None
     t_b0 = time.time()
-    if world > 1:
+    if multi:
         flat = rdist.broadcast_scene(flat, 0, cdev)
     bcast_ms = (time.time() - t_b0) * 1e3
 
     # One context = one HIP stream with its own workspace and copy of the scene. With two, the frames
     # alternate between them, so the tail of one frame's kernels overlaps the start of the next frame's.
     ctxs = []
-    n_contexts = args.contexts if args.contexts > 0 else (1 if world == 1 else 3)
+    n_contexts = args.contexts if args.contexts > 0 else (3 if multi else 1)
     for _ in range(n_contexts):
         c = rtx.Context(dev_index)
         if args.no_cost_order:
@@ -131,10 +136,11 @@ def main():
     # N > 1, its slabs travel while frame k renders and frame k - 2 is assembled). Every frame that
     # was enqueued inside the timed region is complete before the clock stops.
     in_flight = max(1, len(ctxs))     # frames enqueued beyond the one being collected
-    ring = in_flight + 2
+    # (sharded runs: two slabs per context, so that a context's recorded frames see the same two buffers again)
+    ring = 2 * len(ctxs) if multi else in_flight + 2
     images = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
-    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
-    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if world > 1 else None
+    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
+    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
     gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
     image = images[0]
     acc = {}
@@ -147,15 +153,25 @@ def main():
         gather_wait[0] = 0.0
 
     def account(st):
-        acc["closest_ms"] += st.closest_ms
-        acc["shadow_ms"] += st.shadow_ms
-        acc["closest_launches"] += st.closest_launches
-        acc["shadow_launches"] += st.shadow_launches
+        if st.closest_ms > 0.0:      # a frame whose traversal launches carried timing events
+            acc["closest_ms"] += st.closest_ms
+            acc["shadow_ms"] += st.shadow_ms
+            acc["closest_launches"] += st.closest_launches
+            acc["shadow_launches"] += st.shadow_launches
+            acc["closest_rays"] += st.primary_rays + st.reflect_rays + st.refract_rays - st.skipped_rays
+            acc["shadow_rays"] += st.shadow_rays
         acc["render_ms"] += st.render_ms
-        acc["closest_rays"] += st.primary_rays + st.reflect_rays + st.refract_rays - st.skipped_rays
-        acc["shadow_rays"] += st.shadow_rays
         acc["traced"] += st.traced_rays
         acc["reference"] += st.reference_rays
+
+    # GPU-side ordering between the library's streams, torch's current stream and RCCL's stream (no host waits):
+    # slab k is read by all-gather k and rewritten by render k + ring; gathered k is written by all-gather k,
+    # read by assembly k and rewritten by all-gather k + ring.
+    lib_streams = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs] if (multi and not gloo) else None
+    TIMED_EVERY = 8
+    timing_state = [1] * len(ctxs)
+    gather_done = [None] * ring      # recorded on torch's stream once all-gather k has been waited for there
+    assemble_done = [None] * ring    # recorded on the first context's stream after assembly k
 
     def finish_gather():
         if state["gather"] is None:
@@ -163,33 +179,51 @@ def main():
         work, idx = state["gather"]
         state["gather"] = None
         t_w = time.perf_counter()
-        work.wait()
-        torch.cuda.current_stream().synchronize()
+        work.wait()                                     # torch's current stream waits for the collective
+        ev = torch.cuda.Event()
+        ev.record()
+        gather_done[idx] = ev
+        lib_streams[0].wait_event(ev)                   # ... and so does the stream that assembles
+        ctx.assemble_tiles_async(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+        ev2 = torch.cuda.Event()
+        ev2.record(lib_streams[0])
+        assemble_done[idx] = ev2
         gather_wait[0] += time.perf_counter() - t_w
-        ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
 
     def collect():
         """Collects the oldest frame in flight; for N > 1 sends its slab on its way."""
         account(ctxs[state["collected"] % len(ctxs)].render_wait())
         idx = state["collected"] % ring
         state["collected"] += 1
-        if world == 1:
+        if not multi:
             return
-        finish_gather()            # the frame before it
         if gloo:
             dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
             gathered[idx].copy_(gathered_host)
             torch.cuda.current_stream().synchronize()
             ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
-        else:
-            state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
+            return
+        finish_gather()            # the frame before it
+        if assemble_done[idx] is not None:              # the assembly that last read this gather buffer
+            torch.cuda.current_stream().wait_event(assemble_done[idx])
+        state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
 
     def step():
         k = state["enqueued"]
         state["enqueued"] += 1
-        if world == 1:   # single GPU: the frame is written row-major in place
+        if not multi:   # single GPU: the frame is written row-major in place
             ctxs[k % len(ctxs)].render_device_async(w, h, args.depth, 10, images[k % len(images)].data_ptr())
         else:
+            if lib_streams is not None and gather_done[k % ring] is not None:   # the all-gather that last read this slab
+                lib_streams[k % len(ctxs)].wait_event(gather_done[k % ring])
+            # A rank's share of the frame is small enough for the host's launch calls to matter: most frames are
+            # replayed from a recorded graph (no kernel timing); every TIMED_EVERY-th one is launched plainly with
+            # timing events on its traversal kernels, which is where the per-kernel figures come from.
+            timed = 1 if (k % TIMED_EVERY == 0) else 0
+            c = k % len(ctxs)
+            if timing_state[c] != timed:
+                ctxs[c].set_option("kernel_timing", timed)
+                timing_state[c] = timed
             ctxs[k % len(ctxs)].render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
         if state["enqueued"] - state["collected"] > in_flight:
             collect()
@@ -199,11 +233,15 @@ def main():
             collect()
         finish_gather()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
     reset_acc()
+    if multi and not gloo:      # set-up, like the BVH build: every (context, slab) pair renders once plainly and is recorded once
+        for _ in range(3 * ring):
+            step()
+        sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -213,9 +251,9 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    image = images[(state["enqueued"] - 1) % len(images)] if world == 1 else image
+    image = images[(state["enqueued"] - 1) % len(images)] if not multi else image
     total_traced = acc["traced"]
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -224,7 +262,7 @@ def main():
         total_traced = float(tr.item())
 
     sharded_equal = None
-    if world > 1 and rank == 0:   # outside the timed region: the assembled frame against a single-GPU frame
+    if multi and rank == 0:   # outside the timed region: the assembled frame against a single-GPU frame
         whole = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
         ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
         torch.cuda.synchronize()
@@ -243,7 +281,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_workload = (args.config == 3 and args.grid == 708 and (w, h) == (1920, 1080) and args.depth == 10
-                            and args.spec == 0.0 and args.glass == 0 and world == 1)
+                            and args.spec == 0.0 and args.glass == 0 and not multi)
         if default_workload and os.path.exists(tpath):   # the counters were collected on exactly this workload
             try:
                 with open(tpath) as f:
@@ -284,13 +322,13 @@ def main():
                                    "LBVH traversal, scene and BVH resident in HBM"
                                    % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth,
-                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if world > 1 else "single GPU",
+                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if multi else "single GPU",
                        "frames_in_flight_per_gpu": len(ctxs) + 1},
             "rays_per_frame": total_traced / args.steps,
             "sharded_frame_equals_single_gpu_frame": sharded_equal,
             "device_frame_ms_rank0": acc["render_ms"] / args.steps,
             "build_ms": build["build_ms"], "upload_ms": build["upload_ms"], "scene_broadcast_ms": bcast_ms,
-            "gather_wait_ms_per_step_rank0": (gather_wait[0] / args.steps * 1e3) if world > 1 else None,
+            "gather_wait_ms_per_step_rank0": (gather_wait[0] / args.steps * 1e3) if multi else None,
             "bvh": {k: build[k] for k in ("n_nodes", "n_leaves", "max_depth", "key_bits", "uses_bvh")},
             "kernels": {"closest_ms": acc["closest_ms"] / max(acc["closest_launches"], 1),
                         "shadow_ms": acc["shadow_ms"] / max(acc["shadow_launches"], 1)},
@@ -304,12 +342,12 @@ def main():
                                  "traffic measured with PMC counters (traffic) is far below it and frac can exceed 1: the kernel is "
                                  "bound by VALU issue and dependent-fetch latency, not by HBM"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, w, h, args.depth, 10, args.cpu_stride)
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -148,6 +148,9 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "force_mode"   0 = automatic, 1 = exhaustive kernel, 2 = BVH (takes effect at the next rtx_build)
  *   "batch_pixels" pixels rendered per pass of the ray queues (default 2^24; the workspace is sized by min(this, pixels of the frame))
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
+ *   "graphs"        1 (default): frames rendered through the _async entry points that need no host decision between
+ *                   their launches (one batch, no reflective or transparent material, "kernel_timing" 0) are recorded once as a hipGraph
+ *                   and replayed, which costs the host one call per frame instead of about ten; 0: always plain launches
  *   "kernel_timing" 1 (default): the traversal launches carry timing events (closest_ms, shadow_ms of the statistics);
  *                   0: no events, a frame's launches follow each other a few microseconds closer
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
@@ -236,6 +239,10 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world);
  * into a row-major [h][w][3] image (device memory). */
 int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
                        const uint8_t* d_slabs, uint8_t* d_rgb);
+/* Same, but returns as soon as the work is enqueued on the library's stream (rtx_stream): the
+ * caller orders it against its own streams and collectives with events on that stream. */
+int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
+                             const uint8_t* d_slabs, uint8_t* d_rgb);
 
 /* Diagnostics (no counterpart in the reference): with the "stamps" option set, every
  * wavefront of the last closest-hit launch (kind 0) or shadow launch (kind 1) has

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
-    "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait",
+    "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
 ]
 
 
@@ -144,6 +144,7 @@ def lib():
         L.rtx_tiles_per_rank.argtypes = [u32, u32, u32]
         L.rtx_tiles_per_rank.restype = u64
         L.rtx_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]
+        L.rtx_assemble_tiles_async.argtypes = [vp, u32, u32, u32, vp, vp]
         L.rtx_stream.argtypes = [vp]
         L.rtx_stream.restype = vp
         L.rtx_render_device_async.argtypes = [vp, u32, u32, u32, u32, vp]
@@ -393,6 +394,10 @@ class Context:
 
     def assemble_tiles(self, width, height, world, d_slabs, d_rgb):
         self._check(self._L.rtx_assemble_tiles(self._h, width, height, world, d_slabs, d_rgb))
+
+    def assemble_tiles_async(self, width, height, world, d_slabs, d_rgb):
+        """Enqueues the assembly on the context's stream (see stream()) and returns."""
+        self._check(self._L.rtx_assemble_tiles_async(self._h, width, height, world, d_slabs, d_rgb))
 
 
 def tiles_per_rank(width, height, world):

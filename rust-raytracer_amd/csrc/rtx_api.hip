@@ -89,6 +89,7 @@ void rtx_destroy(rtx_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rtx_clear_graphs(ctx);
     free_list(ctx->scene_allocs);
     free_list(ctx->build_allocs);
     free_list(ctx->work_allocs);
@@ -119,6 +120,7 @@ uint64_t rtx_debug_stamps(rtx_context* ctx, int kind, uint64_t* out, uint64_t ca
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return RTX_ERR_INVALID_ARG;
     const std::string k(key);
+    if (k != "kernel_timing") rtx_clear_graphs(ctx);   // recorded frames depend on the options (timed frames are never recorded)
     if (k == "force_mode") {
         if (value < 0 || value > 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "force_mode must be 0, 1 or 2");
         ctx->opt_force_mode = value;
@@ -126,6 +128,8 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
+    } else if (k == "graphs") {
+        ctx->opt_graphs = value ? 1 : 0;
     } else if (k == "kernel_timing") {
         ctx->opt_kernel_timing = value ? 1 : 0;
     } else if (k == "cost_order") {
@@ -157,6 +161,9 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
         return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor has a NULL array with a non-zero count");
     RTX_HIP(ctx, hipSetDevice(ctx->device));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old scene
+    rtx_clear_graphs(ctx);
+    ctx->hit_fraction = 1.0f;
+    ctx->hit_fraction_known = false;
 
     // prim_ref: reference primitive id -> (kind, index); the id arrays must form a permutation.
     std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
@@ -260,6 +267,7 @@ int rtx_build(rtx_context* ctx, rtx_build_stats* stats) {
     if (!ctx->has_scene) return rtx_fail(ctx, RTX_ERR_NO_SCENE, "no scene has been set (rtx_scene_set)");
     RTX_HIP(ctx, hipSetDevice(ctx->device));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old tree
+    rtx_clear_graphs(ctx);
     int rc = rtx_bvh_build(ctx);
     if (rc != RTX_OK) return rc;
     if (stats) *stats = ctx->build_stats;
@@ -341,6 +349,14 @@ int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTX_OK;
+}
+
+int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world, const uint8_t* d_slabs,
+                             uint8_t* d_rgb) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (width == 0 || height == 0 || world == 0 || !d_slabs || !d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "bad argument");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    return rtx_assemble_impl(ctx, width, height, world, d_slabs, d_rgb);
 }
 
 int rtx_render_device(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth, uint32_t samples, uint8_t* d_rgb,

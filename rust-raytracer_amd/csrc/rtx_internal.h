@@ -137,6 +137,7 @@ struct rtx_context {
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     uint32_t num_cus = 256;
     int32_t opt_tune[4] = {48, 24 + (10 << 8), 4, RTX_LEAF_MAX};
+    bool hit_fraction_known = false;   // a frame of the current scene has been collected
     float hit_fraction = 1.0f;   // share of the last frame's closest-hit rays that hit something
     int64_t opt_stamps = 0;
 
@@ -157,6 +158,16 @@ struct rtx_context {
     };
     AsyncSlot async_slots[2];
     uint32_t async_head = 0, async_count = 0;     // oldest slot, frames waiting
+    // Recorded launch sequences (hipGraph) of single-batch, single-level frames rendered through the async entry
+    // points with kernel timing off: replaying one costs the host one call instead of about ten. Keyed by everything the launches depend on.
+    struct FrameGraph {
+        uint64_t key[8];
+        hipGraphExec_t exec;
+        bool has_shadow;
+    };
+    std::vector<FrameGraph> graphs;
+    uint64_t graph_epoch = 0;
+    int64_t opt_graphs = 1;
     int64_t opt_kernel_timing = 1;   // events on the traversal launches (closest_ms / shadow_ms of the statistics)
     int64_t opt_cost_order = 1;   // level-0 traversal launches hand out their units most expensive first (costs of the previous frame)
     std::vector<std::pair<uint64_t, void*>> order_bufs;   // (kind, batch, capacity) -> UnitOrder
@@ -182,6 +193,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                     int async_slot = -1);
 int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
                           uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, bool direct);
+void rtx_clear_graphs(rtx_context* ctx);   // after anything that changes what a recorded frame would launch
 int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats);
 int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir);
 int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb);

@@ -918,6 +918,7 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
         return RTX_OK;
     }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // frames in flight still use the old workspace
+    rtx_clear_graphs(ctx);
     for (void* p : ctx->work_allocs) (void)hipFree(p);
     ctx->work_allocs.clear();
     ctx->work_batch = 0;
@@ -988,7 +989,10 @@ struct EventPool {
 // Remembers which share of a frame's closest-hit rays hit something (sizes the next shadow launch).
 void note_hit_fraction(rtx_context* ctx, const Ctl& hc, uint64_t primary) {
     const double closest = (double)primary + (double)hc.stat[ST_REFLECT] + (double)hc.stat[ST_REFRACT] - (double)hc.stat[ST_SKIPPED];
-    if (closest >= 1.0) ctx->hit_fraction = (float)std::min(1.0, std::max(1.0 / 256.0, (double)hc.stat[ST_NODES] / closest));
+    if (closest >= 1.0) {
+        ctx->hit_fraction = (float)std::min(1.0, std::max(1.0 / 256.0, (double)hc.stat[ST_NODES] / closest));
+        ctx->hit_fraction_known = true;
+    }
 }
 
 // Counters and event times of a finished frame.
@@ -1017,6 +1021,7 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
     };
     rs.closest_ms = sum_ms(closest_events);
     rs.shadow_ms = sum_ms(shadow_events);
+    (void)hipGetLastError();   // a failed time query must not surface in the caller's next HIP call
     rs.closest_launches = (uint32_t)closest_events.size();
     rs.shadow_launches = (uint32_t)shadow_events.size();
     rs.batches = n_batches;
@@ -1040,20 +1045,28 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
 // launch, because events recorded between launches each cost the stream several idle microseconds.
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    hipExtLaunchKernelGGL(k_trace_queue, dim3(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), dim3(RTX_BLOCK), 0, st,
-                          t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, shade ? wk.chunk_cnt : nullptr);
+    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), block(RTX_BLOCK);
+    uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
+    if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+    else hipLaunchKernelGGL(k_trace_queue, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
+}
+template <bool ANY, bool AREA>
+void launch_shadow_kernel(dim3 grid, hipStream_t st, hipEvent_t t0, hipEvent_t t1, const DevScene& s, const Work& wk, uint32_t depth,
+                          uint32_t n_slots, UnitOrder* uo) {
+    if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+    else hipLaunchKernelGGL((k_shadow<ANY, AREA>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
                    UnitOrder* uo, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
-    const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu)), block(RTX_BLOCK);
-    if (any && area) hipExtLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
-    else if (any) hipExtLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
-    else if (area) hipExtLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
-    else hipExtLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+    const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu));
+    if (any && area) launch_shadow_kernel<true, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
+    else if (any) launch_shadow_kernel<true, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
+    else if (area) launch_shadow_kernel<false, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
+    else launch_shadow_kernel<false, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
 }
 
 // The cost / order buffer of one (kind, batch) pair of level-0 launches; nullptr when the
@@ -1083,6 +1096,17 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
     if (world == 0) return 0;
     const uint64_t tiles = (uint64_t)((width + RTX_TILE - 1) / RTX_TILE) * ((height + RTX_TILE - 1) / RTX_TILE);
     return (tiles + world - 1) / world;
+}
+
+void rtx_clear_graphs(rtx_context* ctx) {
+    if (ctx->graphs.empty()) {
+        ++ctx->graph_epoch;
+        return;
+    }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // a recorded frame may still be running
+    for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+    ctx->graphs.clear();
+    ++ctx->graph_epoch;
 }
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
@@ -1117,8 +1141,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const uint32_t levels = ctx->has_secondary ? depth : std::min<uint32_t>(depth, 1);
     // Row-major frames are painted completely by the kernels (k_shade_a paints the misses);
     // tile slabs have padding that no ray covers, and a depth-0 frame shades nothing.
-    if (!direct || levels == 0)
-        RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
+    const bool clear_first = !direct || levels == 0;
     const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x};
     if (!ctx->pinned) {
         void* p = nullptr;
@@ -1147,7 +1170,62 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     hipEvent_t f0 = ev.next(), f1 = ev.next();
     if (!f0 || !f1) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
     std::vector<std::pair<hipEvent_t, hipEvent_t>> closest_events, shadow_events;
-    RTX_HIP(ctx, hipEventRecord(f0, st));
+
+    // A frame that needs no host decision between its launches (one batch, one level, async entry point) is
+    // recorded once as a graph and replayed afterwards.
+    // (not with kernel timing: events recorded by a graph cannot be read back as times)
+    // (and not before a frame has told how large the shadow launch should be)
+    const bool graphable = slot && ctx->opt_graphs && !ctx->opt_kernel_timing && ctx->hit_fraction_known && single_level && rays_local > 0 &&
+                           rays_local <= batch;
+    rtx_context::FrameGraph* fg = nullptr;
+    struct CaptureGuard {   // a stream must not be left in capture mode on an error path
+        hipStream_t st;
+        bool active = false;
+        ~CaptureGuard() {
+            if (active) {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(st, &g);
+                if (g) (void)hipGraphDestroy(g);
+            }
+        }
+    } capture{st};
+    rtx_context::FrameGraph fresh{};
+    if (graphable) {
+        const uint32_t n0 = (uint32_t)rays_local;
+        // buffers the launches use are created before recording
+        (void)unit_order(ctx, 0, 0, (wk.cap_rays / 64 + kGroup) / kGroup);
+        if (s.n_lights > 0) (void)unit_order(ctx, 1, 0, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup);
+        const uint64_t key[8] = {((uint64_t)w << 32) | h, ((uint64_t)depth << 32) | samples, ((uint64_t)rank << 32) | world,
+                                 (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
+                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu) << 32) |
+                                     trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu),
+                                 (uint64_t)(uintptr_t)wk.ctl, (uint64_t)ctx->graph_epoch};
+        for (auto& g : ctx->graphs)
+            if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;
+        if (fg) {
+            RTX_HIP(ctx, hipEventRecord(f0, st));
+            RTX_HIP(ctx, hipGraphLaunch(fg->exec, st));
+            RTX_HIP(ctx, hipEventRecord(f1, st));
+            slot->deferred = true;
+            slot->f0 = f0;
+            slot->f1 = f1;
+            slot->a = slot->b = slot->c = slot->d = nullptr;
+            slot->has_shadow = fg->has_shadow;
+            slot->primary = primary;
+            return RTX_OK;
+        }
+        std::memcpy(fresh.key, key, sizeof(key));
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            capture.active = true;
+        } else {   // no graphs on this context from now on
+            (void)hipGetLastError();
+            ctx->opt_graphs = 0;
+        }
+    }
+    const bool recording = capture.active;
+    if (!recording) RTX_HIP(ctx, hipEventRecord(f0, st));
+    if (clear_first)
+        RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
     uint32_t n_batches = 0;
     uint64_t cur_batch = batch;
     int rollback = 0;
@@ -1164,25 +1242,25 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
             launch_closest(ctx, wk, 0, n_rays, gen, nullptr, false, st);
         for (uint32_t level = 0; level < levels; ++level) {
-            hipEvent_t a = ev.next(), b = ev.next();
-            if (!a || !b) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+            const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
+            hipEvent_t a = no_kt ? nullptr : ev.next(), b = no_kt ? nullptr : ev.next();
+            if (!no_kt && (!a || !b)) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
             const PrimaryGen& pg = (level == 0) ? gen : no_gen;
             // level-0 launches of unchanged size reuse the unit costs of the previous frame (see UnitOrder)
             const bool ordered = level == 0 && cur_batch == batch;
             UnitOrder* uo0 = ordered ? unit_order(ctx, 0, n_batches - 1, (wk.cap_rays / 64 + kGroup) / kGroup) : nullptr;
             UnitOrder* uo1 = nullptr;
-            const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
-            launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, no_kt ? nullptr : a, no_kt ? nullptr : b);
-            closest_events.emplace_back(no_kt ? nullptr : a, no_kt ? nullptr : b);
+            launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, a, b);
+            closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
                                PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map, uo0);
             if (s.n_lights > 0) {
-                hipEvent_t c = ev.next(), d = ev.next();
-                if (!c || !d) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+                hipEvent_t c = no_kt ? nullptr : ev.next(), d = no_kt ? nullptr : ev.next();
+                if (!no_kt && (!c || !d)) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
                 const uint64_t tasks = (uint64_t)n_rays * n_slots;
                 uo1 = ordered ? unit_order(ctx, 1, n_batches - 1, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup) : nullptr;
-                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st, no_kt ? nullptr : c, no_kt ? nullptr : d);
-                shadow_events.emplace_back(no_kt ? nullptr : c, no_kt ? nullptr : d);
+                launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st, c, d);
+                shadow_events.emplace_back(c, d);
             }
             hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
                                out_map, single_level ? 1 : 0, uo1);
@@ -1206,6 +1284,26 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         // the last batch, the frame-end event)
         const bool last_batch = first + n >= rays_local;
         RTX_HIP(ctx, hipMemcpyAsync(host_ctl, wk.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+        if (recording) {   // close the recording, keep it, and run it as this frame
+            hipGraph_t graph = nullptr;
+            capture.active = false;
+            hipError_t ge = hipStreamEndCapture(st, &graph);
+            if (ge == hipSuccess) ge = hipGraphInstantiate(&fresh.exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ge == hipSuccess) {
+                RTX_HIP(ctx, hipEventRecord(f0, st));
+                ge = hipGraphLaunch(fresh.exec, st);
+            }
+            if (ge != hipSuccess) {   // render the frame the plain way, now and from now on
+                (void)hipGetLastError();
+                if (fresh.exec) (void)hipGraphExecDestroy(fresh.exec);
+                ctx->opt_graphs = 0;
+                return rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, stats, direct, async_slot);
+            }
+            fresh.has_shadow = !shadow_events.empty();
+            if (ctx->graphs.size() >= 32) rtx_clear_graphs(ctx);   // a caller cycling through many buffers: start over
+            ctx->graphs.push_back(fresh);
+        }
         if (last_batch) RTX_HIP(ctx, hipEventRecord(f1, st));
         if (slot && single_level && n_batches == 1 && last_batch) {
             // Nothing in this frame needs the host: leave it in flight, rtx_render_wait collects it.

@@ -231,6 +231,39 @@ def test_launch_sizing_does_not_change_the_frame(big):
         ctx.set_option("tune2", 4)
 
 
+def test_recorded_frames_replay_exactly(big, rtx):
+    """With kernel timing off, async single-level frames are recorded as a graph and replayed. Frames to
+    two buffers and of two sizes, several rounds (so that every one is replayed), changing an option in
+    between (recordings are dropped), and with graphs switched off: always the synchronous frame."""
+    import torch
+    _, ctx = big
+    sizes = ((640, 360), (333, 77))
+    refs = [ctx.render(w, h, 10, 10) for w, h in sizes]
+    ctx.set_option("kernel_timing", 0)
+    try:
+        for graphs in (1, 0, 1):
+            ctx.set_option("graphs", graphs)
+            for rnd in range(4):
+                if rnd == 2:
+                    ctx.set_option("tune0", 40)      # drops the recordings; frames must not change
+                for (w, h), (ref, sr) in zip(sizes, refs):
+                    bufs = [torch.full((h * w * 3,), 5, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+                    for b in bufs:
+                        ctx.render_device_async(w, h, 10, 10, b.data_ptr())
+                    for b in bufs:
+                        st = ctx.render_wait()
+                        assert (st.primary_rays, st.shadow_rays, st.shaded_nodes) == (sr.primary_rays, sr.shadow_rays, sr.shaded_nodes)
+                        assert st.closest_ms == 0.0 and st.render_ms > 0
+                    torch.cuda.synchronize()
+                    for b in bufs:
+                        assert np.array_equal(b.cpu().numpy().reshape(h, w, 3), ref)
+                    del bufs
+    finally:
+        ctx.set_option("tune0", 48)
+        ctx.set_option("graphs", 1)
+        ctx.set_option("kernel_timing", 1)
+
+
 def test_kernel_timing_option(big):
     """kernel_timing 0 drops the events on the traversal launches: same frame and counts,
     closest_ms / shadow_ms are reported as 0, the launch counts stay."""
