@@ -286,8 +286,22 @@ RTX_D void order_units(UnitOrder* uo) {
     if (t == 0) s_max = 1;
     for (int k = 0; k < kOrderClasses; ++k) offs[k * kOrderThreads + t] = 0;
     __syncthreads();
+    // A thread's costs are read once, with independent loads, when they fit its registers (the usual case):
+    // the sort runs inside a shading kernel that may be short, so its own latency counts.
+    constexpr uint32_t kHeld = 16;
+    uint32_t held[kHeld];
+    const bool fits = per <= kHeld;
+    if (fits) {
+#pragma unroll
+        for (uint32_t k = 0; k < kHeld; ++k) held[k] = (lo + k < hi) ? cost[lo + k] : 0u;
+    }
     uint32_t mx = 1;
-    for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost[u]);
+    if (fits) {
+#pragma unroll
+        for (uint32_t k = 0; k < kHeld; ++k) mx = max(mx, held[k]);
+    } else {
+        for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost[u]);
+    }
     atomicMax(&s_max, mx);
     __syncthreads();
     const int top = 2 * (31 - __clz((int)s_max)) + 1;
@@ -297,7 +311,13 @@ RTX_D void order_units(UnitOrder* uo) {
         const int half = (e > 0) ? (int)((c >> (e - 1)) & 1u) : 0;
         return min(kOrderClasses - 1, top - (2 * e + half));
     };
-    for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost[u]) * kOrderThreads + t];
+    if (fits) {
+#pragma unroll
+        for (uint32_t k = 0; k < kHeld; ++k)
+            if (lo + k < hi) ++offs[cls(held[k]) * kOrderThreads + t];
+    } else {
+        for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost[u]) * kOrderThreads + t];
+    }
     __syncthreads();
     // Exclusive scan of the class-major, thread-minor sequence in place; thread t scans the
     // 16 consecutive entries [16 t, 16 t + 16).
@@ -318,14 +338,33 @@ RTX_D void order_units(UnitOrder* uo) {
     for (uint32_t w = 0; w < (t >> 6); ++w) base += wave_sum[w];
     for (int k = 0; k < kOrderClasses; ++k) offs[t * kOrderClasses + k] += base;
     __syncthreads();
-    for (uint32_t u = lo; u < hi; ++u) {
-        order[offs[cls(cost[u]) * kOrderThreads + t]++] = u;
-        cost[u] = 0;
+    if (fits) {
+#pragma unroll
+        for (uint32_t k = 0; k < kHeld; ++k) {
+            if (lo + k < hi) {
+                order[offs[cls(held[k]) * kOrderThreads + t]++] = lo + k;
+                cost[lo + k] = 0;
+            }
+        }
+    } else {
+        for (uint32_t u = lo; u < hi; ++u) {
+            order[offs[cls(cost[u]) * kOrderThreads + t]++] = u;
+            cost[u] = 0;
+        }
     }
     __syncthreads();
     if (t == 0) uo->n_order = n_units;
     __syncthreads();
 }
+
+// k_shade_a turns hits into shading nodes in chunks of RTX_BLOCK * kShadeItems consecutive rays
+// (= 1 << kChunkUnitsLog2 work units of the closest-hit kernel, which counts the hits per chunk).
+#ifndef RTX_SHADE_ITEMS
+#define RTX_SHADE_ITEMS 4
+#endif
+constexpr int kShadeItems = RTX_SHADE_ITEMS;
+constexpr int kChunkUnitsLog2 = (kShadeItems == 8) ? 5 : (kShadeItems == 4) ? 4 : (kShadeItems == 2) ? 3 : 2;
+static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_shade_a is a power-of-two number of units");
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
@@ -365,7 +404,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
         const uint64_t hits = __ballot(i < n && id >= 0);
-        if (chunk_cnt && hits && (threadIdx.x & 63) == 0) atomicAdd(&chunk_cnt[unit >> 5], (uint32_t)__popcll(hits));   // 32 units = one chunk of k_shade_a
+        if (chunk_cnt && hits && (threadIdx.x & 63) == 0) atomicAdd(&chunk_cnt[unit >> kChunkUnitsLog2], (uint32_t)__popcll(hits));
         uq.record(unit, unit_start);
 #ifdef RTX_COUNT_STEPS
         ws.add_steps(st.steps);
@@ -426,8 +465,6 @@ RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as
 // the chunks before it (k_scan_chunks over the counts the traversal kernel took), and inside
 // the chunk slots follow the ray order, so the node order is the ray order: no atomics, and
 // the same frame gives the same order every time.
-constexpr int kShadeItems = 8;
-static_assert(RTX_BLOCK * kShadeItems == 64 * 32, "a chunk of k_shade_a is 32 units of the closest-hit kernel");
 
 // Exclusive prefix of the per-chunk hit counts (one workgroup; at most a few thousand chunks);
 // sets the level's node count and clears the counts for the next launch.
