@@ -93,6 +93,7 @@ void rtx_destroy(rtx_context* ctx) {
     free_list(ctx->scene_allocs);
     free_list(ctx->build_allocs);
     free_list(ctx->work_allocs);
+    if (ctx->build_arena) (void)hipFree(ctx->build_arena);
     for (auto& e : ctx->order_bufs) (void)hipFree(e.second);
     ctx->order_bufs.clear();
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);

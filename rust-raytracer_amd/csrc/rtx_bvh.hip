@@ -387,8 +387,9 @@ __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__
                                                           float4* __restrict__ nmin, float4* __restrict__ nmax,
                                                           const int* __restrict__ parent, uint32_t* __restrict__ counter,
                                                           uint8_t* __restrict__ theight, int* __restrict__ qout,
-                                                          uint32_t* __restrict__ qout_count, int leaf_max) {
+                                                          uint32_t* __restrict__ qout_count, int leaf_max, uint32_t* __restrict__ n_levels) {
     const uint32_t cnt = *qin_count;
+    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the root find an empty queue
     for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += gridDim.x * kThreads) {
         const int i = qin[k];
         const int l = child_l[i], r = child_r[i];
@@ -450,14 +451,14 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
                                                      const int* __restrict__ rng_first,
                                                      const int* __restrict__ rng_last, const float4* __restrict__ nmin,
                                                      const float4* __restrict__ nmax, BvhNode* __restrict__ nodes,
-                                                     uint32_t* __restrict__ counts, int leaf_max) {
+                                                     uint32_t* __restrict__ counts, int leaf_max, uint32_t* __restrict__ n_levels) {
     __shared__ uint32_t s_nodes, s_leaves;
     if (threadIdx.x == 0) s_nodes = s_leaves = 0;
     __syncthreads();
-    const uint32_t slot = blockIdx.x * kThreads + threadIdx.x;
     uint32_t my_nodes = 0, my_leaves = 0;
-    const bool emit = slot < *qin_count;
-    if (emit) {
+    const uint32_t cnt = *qin_count;
+    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the last level find an empty queue
+    for (uint32_t slot = blockIdx.x * kThreads + threadIdx.x; slot < cnt; slot += gridDim.x * kThreads) {
         const int i = qin[slot];
         int ch[4] = {child_l[i], child_r[i], 0, 0};
         int nc = 2;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
         nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
         nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], rcode[0] | (rcode[1] << 16), rcode[2] | (rcode[3] << 16));
         nodes[i] = nd;
-        my_nodes = 1;
+        ++my_nodes;
     }
     if (my_nodes) atomicAdd(&s_nodes, my_nodes);     // LDS atomics
     if (my_leaves) atomicAdd(&s_leaves, my_leaves);
@@ -578,6 +579,24 @@ int dev_alloc(rtx_context* ctx, std::vector<void*>& owner, T** out, size_t count
     return RTX_OK;
 }
 
+// Temporaries of a build: carved out of one arena, hipMalloc for what does not fit.
+struct TmpArena {
+    rtx_context* ctx;
+    std::vector<void*> extra;   // fallbacks, freed at the end
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    template <typename T>
+    int get(T** out, size_t count) {
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes <= size) {
+            *out = (T*)(base + used);
+            used += bytes;
+            return RTX_OK;
+        }
+        return dev_alloc(ctx, extra, out, count);
+    }
+};
+
 inline uint32_t grid_for(uint64_t n, uint32_t cap = 4096) {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kThreads - 1) / kThreads, cap));
 }
@@ -600,8 +619,35 @@ int rtx_bvh_build(rtx_context* ctx) {
     RTX_HIP(ctx, hipEventCreate(&ev1));
     RTX_HIP(ctx, hipEventRecord(ev0, st));
 
-    std::vector<void*> tmp;   // freed at the end
-    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); tmp.clear(); };
+    // Temporaries come out of one arena (a dozen hipMalloc calls cost more than the kernels of a 1 M-primitive
+    // build); it stays with the context for the next build unless it is large. What does not fit falls back to hipMalloc.
+    TmpArena tmp{ctx};
+    {
+        const size_t want = (size_t)n * 200 + (8u << 20);
+        if (ctx->build_arena_size < want) {
+            if (ctx->build_arena) (void)hipFree(ctx->build_arena);
+            ctx->build_arena = nullptr;
+            ctx->build_arena_size = 0;
+            void* p = nullptr;
+            if (hipMalloc(&p, want) == hipSuccess) {
+                ctx->build_arena = p;
+                ctx->build_arena_size = want;
+            } else {
+                (void)hipGetLastError();   // piecewise allocation below may still fit
+            }
+        }
+        tmp.base = (char*)ctx->build_arena;
+        tmp.size = ctx->build_arena_size;
+    }
+    auto cleanup = [&]() {
+        for (void* p : tmp.extra) (void)hipFree(p);
+        tmp.extra.clear();
+        if (ctx->build_arena_size > ((size_t)1 << 30)) {   // do not sit on gigabytes between builds
+            (void)hipFree(ctx->build_arena);
+            ctx->build_arena = nullptr;
+            ctx->build_arena_size = 0;
+        }
+    };
 #define TRY(x) do { int rc_ = (x); if (rc_ != RTX_OK) { cleanup(); return rc_; } } while (0)
 #define TRY_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); \
         return rtx_fail(ctx, RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -613,9 +659,9 @@ int rtx_bvh_build(rtx_context* ctx) {
     // Scene bounds are needed in both modes (safe region of the padded tests).
     float4 *bmin = nullptr, *bmax = nullptr;
     SceneBounds* sb = nullptr;
-    TRY(dev_alloc(ctx, tmp, &bmin, n));
-    TRY(dev_alloc(ctx, tmp, &bmax, n));
-    TRY(dev_alloc(ctx, tmp, &sb, 1));
+    TRY(tmp.get(&bmin, n));
+    TRY(tmp.get(&bmax, n));
+    TRY(tmp.get(&sb, 1));
     SceneBounds init;
     for (int k = 0; k < 3; ++k) { init.cmin[k] = init.bmin[k] = 0xFFFFFFFFu; init.cmax[k] = init.bmax[k] = 0u; }
     TRY_HIP(hipMemcpyAsync(sb, &init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -675,15 +721,15 @@ int rtx_bvh_build(rtx_context* ctx) {
         }
         uint64_t* keys[2];
         uint32_t* vals[2];
-        for (int k = 0; k < 2; ++k) { TRY(dev_alloc(ctx, tmp, &keys[k], n)); TRY(dev_alloc(ctx, tmp, &vals[k], n)); }
+        for (int k = 0; k < 2; ++k) { TRY(tmp.get(&keys[k], n)); TRY(tmp.get(&vals[k], n)); }
         hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, mp, keys[0], vals[0]);
 
         const uint32_t nb = (n + kSortTile - 1) / kSortTile;
         const uint32_t m = 256u * nb;
         const uint32_t np = (m + kScanChunk - 1) / kScanChunk;
         uint32_t *hist = nullptr, *partial = nullptr;
-        TRY(dev_alloc(ctx, tmp, &hist, m));
-        TRY(dev_alloc(ctx, tmp, &partial, np));
+        TRY(tmp.get(&hist, m));
+        TRY(tmp.get(&partial, np));
         int cur = 0;
         for (int shift = 0; shift < 3 * bits; shift += 8) {
             hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kThreads), 0, st, keys[cur], n, shift, hist, nb);
@@ -702,39 +748,44 @@ int rtx_bvh_build(rtx_context* ctx) {
         uint8_t* theight;
         float4 *nmin, *nmax;
         const size_t total = 2 * (size_t)n - 1;
-        TRY(dev_alloc(ctx, tmp, &child_l, n - 1));
-        TRY(dev_alloc(ctx, tmp, &child_r, n - 1));
-        TRY(dev_alloc(ctx, tmp, &rng_first, n - 1));
-        TRY(dev_alloc(ctx, tmp, &rng_last, n - 1));
-        TRY(dev_alloc(ctx, tmp, &parent, total));
-        TRY(dev_alloc(ctx, tmp, &counter, n - 1));
-        TRY(dev_alloc(ctx, tmp, &theight, total));
-        TRY(dev_alloc(ctx, tmp, &nmin, total));
-        TRY(dev_alloc(ctx, tmp, &nmax, total));
-        TRY(dev_alloc(ctx, tmp, &queue[0], n));
-        TRY(dev_alloc(ctx, tmp, &queue[1], n));
-        TRY(dev_alloc(ctx, tmp, &qcount, 2));
-        TRY(dev_alloc(ctx, tmp, &counts, 2));
+        TRY(tmp.get(&child_l, n - 1));
+        TRY(tmp.get(&child_r, n - 1));
+        TRY(tmp.get(&rng_first, n - 1));
+        TRY(tmp.get(&rng_last, n - 1));
+        TRY(tmp.get(&parent, total));
+        TRY(tmp.get(&counter, n - 1));
+        TRY(tmp.get(&theight, total));
+        TRY(tmp.get(&nmin, total));
+        TRY(tmp.get(&nmax, total));
+        TRY(tmp.get(&queue[0], n));
+        TRY(tmp.get(&queue[1], n));
+        TRY(tmp.get(&qcount, 2));
+        TRY(tmp.get(&counts, 4));   // nodes, leaves, refit levels, emission levels
         TRY_HIP(hipMemsetAsync(counter, 0, (size_t)(n - 1) * 4, st));
         TRY_HIP(hipMemsetAsync(qcount, 0, 8, st));
-        TRY_HIP(hipMemsetAsync(counts, 0, 8, st));
+        TRY_HIP(hipMemsetAsync(counts, 0, 16, st));
         hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, child_l,
                            child_r, parent, rng_first, rng_last);
         hipLaunchKernelGGL(k_leaf_init, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax,
                            nmin, nmax, parent, counter, theight, queue[0], &qcount[0], pp);
-        // Refit: one launch per level until the queue drains (the root pushes nothing).
+        // Refit: one launch per level until the queue drains (the root pushes nothing). The host looks at the
+        // queue only every kLevelBatch launches; a launch that finds its queue empty does nothing.
+        constexpr int kLevelBatch = 8;
+        const uint32_t level_grid = (uint32_t)std::min<uint64_t>(grid_for(n), 2048);
         int q = 0;
         uint32_t levels = 0;
-        for (;;) {
+        for (int round = 0;; ++round) {
+            for (int b = 0; b < kLevelBatch; ++b) {
+                TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
+                hipLaunchKernelGGL(k_refit_pass, dim3(level_grid), dim3(kThreads), 0, st, queue[q], &qcount[q], child_l, child_r, rng_first,
+                                   rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1], leaf_max, &counts[2]);
+                q ^= 1;
+            }
             uint32_t cnt = 0;
             TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
             TRY_HIP(hipStreamSynchronize(st));
             if (cnt == 0) break;
-            if (++levels > 4096) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
-            TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
-            hipLaunchKernelGGL(k_refit_pass, dim3(grid_for(cnt)), dim3(kThreads), 0, st, queue[q], &qcount[q], child_l, child_r,
-                               rng_first, rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1], leaf_max);
-            q ^= 1;
+            if (round > 512) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
         }
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
@@ -746,27 +797,30 @@ int rtx_bvh_build(rtx_context* ctx) {
             q = 0;
             TRY_HIP(hipMemcpyAsync(queue[0], &root, 4, hipMemcpyHostToDevice, st));
             TRY_HIP(hipMemcpyAsync(&qcount[0], &one, 4, hipMemcpyHostToDevice, st));
-            for (;;) {
+            for (int round = 0;; ++round) {
+                for (int b = 0; b < kLevelBatch; ++b) {
+                    TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
+                    hipLaunchKernelGGL(k_emit4, dim3(level_grid), dim3(kThreads), 0, st, (int)n, queue[q], &qcount[q], queue[q ^ 1],
+                                       &qcount[q ^ 1], child_l, child_r, rng_first, rng_last, nmin, nmax, nodes, counts, leaf_max, &counts[3]);
+                    q ^= 1;
+                }
                 uint32_t cnt = 0;
                 TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
                 TRY_HIP(hipStreamSynchronize(st));
                 if (cnt == 0) break;
-                if (++levels4 > 4096) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
-                TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
-                hipLaunchKernelGGL(k_emit4, dim3((cnt + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, queue[q], &qcount[q],
-                                   queue[q ^ 1], &qcount[q ^ 1], child_l, child_r, rng_first, rng_last, nmin, nmax, nodes, counts,
-                                   leaf_max);
-                q ^= 1;
+                if (round > 512) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
             }
         }
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
-        uint32_t hcounts[2] = {0, 0};
+        uint32_t hcounts[4] = {0, 0, 0, 0};
         uint8_t root_h = 0;
-        TRY_HIP(hipMemcpyAsync(hcounts, counts, 8, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipMemcpyAsync(hcounts, counts, 16, hipMemcpyDeviceToHost, st));
         TRY_HIP(hipMemcpyAsync(&root_h, theight, 1, hipMemcpyDeviceToHost, st));
         TRY_HIP(hipStreamSynchronize(st));
         bs.n_nodes = hcounts[0];
         bs.n_leaves = hcounts[1];
+        levels = hcounts[2];
+        levels4 = hcounts[3];
         (void)root_h;
         bs.max_depth = levels;   // height of the binary tree; the 4-wide tree has about half of it
         s.recs = recs;
