@@ -299,10 +299,22 @@ __device__ __forceinline__ int kdelta(const uint64_t* __restrict__ keys, int n, 
     if (a == b) return 64 + __clz((unsigned)(i ^ j));   // duplicate keys: fall back to the position
     return __clzll((long long)(a ^ b));
 }
+// Everything hierarchy construction, refit and emission keep about one node of the binary tree, in one
+// 64-byte line: those kernels follow parent / child links, so a node's fields are wanted together.
+struct alignas(64) BuildNode {
+    float4 mn;              // padded box minimum; w = smallest sphere radius below (+inf: none)
+    float4 mx;              // padded box maximum
+    int l, r;               // children (inner nodes)
+    int first, last;        // range of sorted primitives (inner nodes)
+    int parent;             // -1 for the root
+    uint32_t counter;       // children that have reported during refit
+    uint32_t height;        // 0 for a leaf or a subtree that becomes one
+    uint32_t pad;
+};
+static_assert(sizeof(BuildNode) == 64, "one line per node");
+
 // Node ids: internal i in [0, n-1) -> i ; leaf j in [0, n) -> (n-1) + j.
-__global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict__ keys, int n, int* __restrict__ child_l,
-                                                      int* __restrict__ child_r, int* __restrict__ parent,
-                                                      int* __restrict__ rng_first, int* __restrict__ rng_last) {
+__global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict__ keys, int n, BuildNode* __restrict__ bn) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n - 1) return;
     const int d = (kdelta(keys, n, i, i + 1) - kdelta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -323,13 +335,14 @@ __global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict_
     const int lo = min(i, j), hi = max(i, j);
     const int left = (lo == gamma) ? (n - 1) + gamma : gamma;
     const int right = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
-    child_l[i] = left;
-    child_r[i] = right;
-    parent[left] = i;
-    parent[right] = i;
-    rng_first[i] = lo;
-    rng_last[i] = hi;
-    if (i == 0) parent[0] = -1;
+    bn[i].l = left;
+    bn[i].r = right;
+    bn[i].first = lo;
+    bn[i].last = hi;
+    bn[i].counter = 0;
+    bn[left].parent = i;
+    bn[right].parent = i;
+    if (i == 0) bn[0].parent = -1;
 }
 
 struct PadParams {
@@ -350,12 +363,10 @@ __device__ __forceinline__ uint32_t f16_bits_down(float r) {
 // ray passing marginally outside the exact shape (f32 rounding in
 // Moeller-Trumbore). The sphere discriminant's cancellation error grows with the
 // distance between ray origin and centre; it is covered at traversal time from
-// the smallest sphere radius of each subtree, carried in nmin[].w (+inf: no sphere).
+// the smallest sphere radius of each subtree, carried in BuildNode::mn.w (+inf: no sphere).
 __global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
                                                          const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                                                         float4* __restrict__ nmin, float4* __restrict__ nmax,
-                                                         const int* __restrict__ parent, uint32_t* __restrict__ counter,
-                                                         uint8_t* __restrict__ theight, int* __restrict__ queue,
+                                                         BuildNode* __restrict__ bn, int* __restrict__ queue,
                                                          uint32_t* __restrict__ qcount, PadParams pp) {
     const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
     if (j >= n) return;
@@ -370,56 +381,50 @@ __global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, 
         if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
     }
     const uint32_t node = (n - 1) + j;
-    nmin[node] = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
-    nmax[node] = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
-    theight[node] = 0;
+    bn[node].mn = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
+    bn[node].mx = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
+    bn[node].height = 0;
     if (n > 1) {
-        const int p = parent[node];
-        if (atomicAdd(&counter[p], 1u) == 1u) queue[atomicAdd(qcount, 1u)] = p;
+        const int p = bn[node].parent;
+        if (atomicAdd(&bn[p].counter, 1u) == 1u) queue[atomicAdd(qcount, 1u)] = p;
     }
 }
 
 // One tree level per launch: every node in `qin` has both children finished by
 // earlier launches, so their boxes are visible without in-kernel fences.
 __global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
-                                                          const int* __restrict__ child_l, const int* __restrict__ child_r,
-                                                          const int* __restrict__ rng_first, const int* __restrict__ rng_last,
-                                                          float4* __restrict__ nmin, float4* __restrict__ nmax,
-                                                          const int* __restrict__ parent, uint32_t* __restrict__ counter,
-                                                          uint8_t* __restrict__ theight, int* __restrict__ qout,
+                                                          BuildNode* __restrict__ bn, int* __restrict__ qout,
                                                           uint32_t* __restrict__ qout_count, int leaf_max, uint32_t* __restrict__ n_levels) {
     const uint32_t cnt = *qin_count;
     if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the root find an empty queue
     for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += gridDim.x * kThreads) {
         const int i = qin[k];
-        const int l = child_l[i], r = child_r[i];
-        const float4 la = nmin[l], lb = nmax[l], ra = nmin[r], rb = nmax[r];
-        nmin[i] = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), fminf(la.w, ra.w));  // BoundingBox + , shapes/mod.rs:86-104
-        nmax[i] = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
-        const int size = rng_last[i] - rng_first[i] + 1;
-        const int h = (size <= leaf_max) ? 0 : 1 + max((int)theight[l], (int)theight[r]);
-        theight[i] = (uint8_t)min(h, 255);
-        const int p = parent[i];
-        if (p >= 0 && atomicAdd(&counter[p], 1u) == 1u) qout[atomicAdd(qout_count, 1u)] = p;
+        const int l = bn[i].l, r = bn[i].r;
+        const float4 la = bn[l].mn, lb = bn[l].mx, ra = bn[r].mn, rb = bn[r].mx;
+        bn[i].mn = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), fminf(la.w, ra.w));  // BoundingBox + , shapes/mod.rs:86-104
+        bn[i].mx = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
+        const int size = bn[i].last - bn[i].first + 1;
+        const int h = (size <= leaf_max) ? 0 : 1 + (int)max(bn[l].height, bn[r].height);
+        bn[i].height = (uint32_t)min(h, 255);
+        const int p = bn[i].parent;
+        if (p >= 0 && atomicAdd(&bn[p].counter, 1u) == 1u) qout[atomicAdd(qout_count, 1u)] = p;
     }
 }
 
 // Reference to binary node c as a child of a traversal node: a leaf (single primitive
 // or a collapsed subtree of at most leaf_max primitives) or an inner node.
-__device__ __forceinline__ bool is_expandable(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
-                                              int leaf_max) {
-    return c < n - 1 && (rng_last[c] - rng_first[c] + 1) > leaf_max;
+__device__ __forceinline__ bool is_expandable(int c, int n, const BuildNode* __restrict__ bn, int leaf_max) {
+    return c < n - 1 && (bn[c].last - bn[c].first + 1) > leaf_max;
 }
-__device__ __forceinline__ int child_ref(int c, int n, const int* __restrict__ rng_first, const int* __restrict__ rng_last,
-                                         uint32_t* leaf_count, int leaf_max) {
+__device__ __forceinline__ int child_ref(int c, int n, const BuildNode* __restrict__ bn, uint32_t* leaf_count, int leaf_max) {
     if (c >= n - 1) {
         ++*leaf_count;
         return (int)~(((uint32_t)(c - (n - 1)) << 3) | 0u);
     }
-    const int size = rng_last[c] - rng_first[c] + 1;
+    const int first = bn[c].first, size = bn[c].last - first + 1;
     if (size <= leaf_max) {
         ++*leaf_count;
-        return (int)~(((uint32_t)rng_first[c] << 3) | (uint32_t)(size - 1));
+        return (int)~(((uint32_t)first << 3) | (uint32_t)(size - 1));
     }
     return c;
 }
@@ -447,10 +452,7 @@ __device__ __forceinline__ float half_area(const float4& mn, const float4& mx) {
 }
 __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
                                                      int* __restrict__ qout, uint32_t* __restrict__ qout_count,
-                                                     const int* __restrict__ child_l, const int* __restrict__ child_r,
-                                                     const int* __restrict__ rng_first,
-                                                     const int* __restrict__ rng_last, const float4* __restrict__ nmin,
-                                                     const float4* __restrict__ nmax, BvhNode* __restrict__ nodes,
+                                                     const BuildNode* __restrict__ bn, BvhNode* __restrict__ nodes,
                                                      uint32_t* __restrict__ counts, int leaf_max, uint32_t* __restrict__ n_levels) {
     __shared__ uint32_t s_nodes, s_leaves;
     if (threadIdx.x == 0) s_nodes = s_leaves = 0;
@@ -460,14 +462,14 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
     if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the last level find an empty queue
     for (uint32_t slot = blockIdx.x * kThreads + threadIdx.x; slot < cnt; slot += gridDim.x * kThreads) {
         const int i = qin[slot];
-        int ch[4] = {child_l[i], child_r[i], 0, 0};
+        int ch[4] = {bn[i].l, bn[i].r, 0, 0};
         int nc = 2;
         while (nc < 4) {
             int best = -1;
             float best_area = -1.0f;
             for (int k = 0; k < nc; ++k) {
-                if (!is_expandable(ch[k], n, rng_first, rng_last, leaf_max)) continue;
-                const float a = half_area(nmin[ch[k]], nmax[ch[k]]);
+                if (!is_expandable(ch[k], n, bn, leaf_max)) continue;
+                const float a = half_area(bn[ch[k]].mn, bn[ch[k]].mx);
                 if (!(a <= best_area)) {   // also takes a NaN area rather than stopping early
                     best = k;
                     best_area = a;
@@ -475,10 +477,10 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
             }
             if (best < 0) break;
             const int c = ch[best];
-            ch[best] = child_l[c];
-            ch[nc++] = child_r[c];
+            ch[best] = bn[c].l;
+            ch[nc++] = bn[c].r;
         }
-        const float4 bmn = nmin[i], bmx = nmax[i];
+        const float4 bmn = bn[i].mn, bmx = bn[i].mx;
         const float org[3] = {bmn.x, bmn.y, bmn.z};
         const float ext[3] = {bmx.x - bmn.x, bmx.y - bmn.y, bmx.z - bmn.z};
         uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, eb[3];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
         uint32_t rcode[4] = {0x7c00u, 0x7c00u, 0x7c00u, 0x7c00u};   // smallest sphere radius per child, f16; +inf = none
         bool spheres = false;
         for (int k = 0; k < nc; ++k) {
-            const float4 a = nmin[ch[k]], b = nmax[ch[k]];
+            const float4 a = bn[ch[k]].mn, b = bn[ch[k]].mx;
             if (a.w < __builtin_inff()) {
                 rcode[k] = f16_bits_down(a.w);
                 spheres = true;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict
         }
         int ref[4] = {0, 0, 0, 0};
         for (int k = 0; k < nc; ++k) {
-            ref[k] = child_ref(ch[k], n, rng_first, rng_last, &my_leaves, leaf_max);
+            ref[k] = child_ref(ch[k], n, bn, &my_leaves, leaf_max);
             if (ref[k] >= 0) qout[atomicAdd(qout_count, 1u)] = ref[k];   // roots a node of the next level
         }
         BvhNode nd;
@@ -623,7 +625,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     // build); it stays with the context for the next build unless it is large. What does not fit falls back to hipMalloc.
     TmpArena tmp{ctx};
     {
-        const size_t want = (size_t)n * 200 + (8u << 20);
+        const size_t want = (size_t)n * 224 + (8u << 20);
         if (ctx->build_arena_size < want) {
             if (ctx->build_arena) (void)hipFree(ctx->build_arena);
             ctx->build_arena = nullptr;
@@ -743,31 +745,20 @@ int rtx_bvh_build(rtx_context* ctx) {
         const uint64_t* skeys = keys[cur];
         const uint32_t* sids = vals[cur];
 
-        int *child_l, *child_r, *parent, *rng_first, *rng_last, *queue[2];
-        uint32_t *counter, *qcount, *counts;
-        uint8_t* theight;
-        float4 *nmin, *nmax;
+        int* queue[2];
+        uint32_t *qcount, *counts;
+        BuildNode* bn;
         const size_t total = 2 * (size_t)n - 1;
-        TRY(tmp.get(&child_l, n - 1));
-        TRY(tmp.get(&child_r, n - 1));
-        TRY(tmp.get(&rng_first, n - 1));
-        TRY(tmp.get(&rng_last, n - 1));
-        TRY(tmp.get(&parent, total));
-        TRY(tmp.get(&counter, n - 1));
-        TRY(tmp.get(&theight, total));
-        TRY(tmp.get(&nmin, total));
-        TRY(tmp.get(&nmax, total));
+        TRY(tmp.get(&bn, total));
         TRY(tmp.get(&queue[0], n));
         TRY(tmp.get(&queue[1], n));
         TRY(tmp.get(&qcount, 2));
         TRY(tmp.get(&counts, 4));   // nodes, leaves, refit levels, emission levels
-        TRY_HIP(hipMemsetAsync(counter, 0, (size_t)(n - 1) * 4, st));
         TRY_HIP(hipMemsetAsync(qcount, 0, 8, st));
         TRY_HIP(hipMemsetAsync(counts, 0, 16, st));
-        hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, child_l,
-                           child_r, parent, rng_first, rng_last);
-        hipLaunchKernelGGL(k_leaf_init, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax,
-                           nmin, nmax, parent, counter, theight, queue[0], &qcount[0], pp);
+        hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, bn);
+        hipLaunchKernelGGL(k_leaf_init, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax, bn, queue[0],
+                           &qcount[0], pp);
         // Refit: one launch per level until the queue drains (the root pushes nothing). The host looks at the
         // queue only every kLevelBatch launches; a launch that finds its queue empty does nothing.
         constexpr int kLevelBatch = 8;
@@ -777,8 +768,8 @@ int rtx_bvh_build(rtx_context* ctx) {
         for (int round = 0;; ++round) {
             for (int b = 0; b < kLevelBatch; ++b) {
                 TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
-                hipLaunchKernelGGL(k_refit_pass, dim3(level_grid), dim3(kThreads), 0, st, queue[q], &qcount[q], child_l, child_r, rng_first,
-                                   rng_last, nmin, nmax, parent, counter, theight, queue[q ^ 1], &qcount[q ^ 1], leaf_max, &counts[2]);
+                hipLaunchKernelGGL(k_refit_pass, dim3(level_grid), dim3(kThreads), 0, st, queue[q], &qcount[q], bn, queue[q ^ 1],
+                                   &qcount[q ^ 1], leaf_max, &counts[2]);
                 q ^= 1;
             }
             uint32_t cnt = 0;
@@ -801,7 +792,7 @@ int rtx_bvh_build(rtx_context* ctx) {
                 for (int b = 0; b < kLevelBatch; ++b) {
                     TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
                     hipLaunchKernelGGL(k_emit4, dim3(level_grid), dim3(kThreads), 0, st, (int)n, queue[q], &qcount[q], queue[q ^ 1],
-                                       &qcount[q ^ 1], child_l, child_r, rng_first, rng_last, nmin, nmax, nodes, counts, leaf_max, &counts[3]);
+                                       &qcount[q ^ 1], bn, nodes, counts, leaf_max, &counts[3]);
                     q ^= 1;
                 }
                 uint32_t cnt = 0;
@@ -813,15 +804,12 @@ int rtx_bvh_build(rtx_context* ctx) {
         }
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
         uint32_t hcounts[4] = {0, 0, 0, 0};
-        uint8_t root_h = 0;
         TRY_HIP(hipMemcpyAsync(hcounts, counts, 16, hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipMemcpyAsync(&root_h, theight, 1, hipMemcpyDeviceToHost, st));
         TRY_HIP(hipStreamSynchronize(st));
         bs.n_nodes = hcounts[0];
         bs.n_leaves = hcounts[1];
         levels = hcounts[2];
         levels4 = hcounts[3];
-        (void)root_h;
         bs.max_depth = levels;   // height of the binary tree; the 4-wide tree has about half of it
         s.recs = recs;
         s.nodes = nodes;
