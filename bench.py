@@ -342,7 +342,7 @@ def main():
                                  "traffic measured with PMC counters (traffic) is far below it and frac can exceed 1: the kernel is "
                                  "bound by VALU issue and dependent-fetch latency, not by HBM"},
         }
-        if not multi and len(ctxs) == 1:
+        if default_workload and len(ctxs) == 1:
             # Supplementary, outside the timed region and not `value`: the same frames alternating between three
             # contexts (streams), where one frame's kernel tails overlap the next frame's kernels. The headline run
             # uses one context so that its per-kernel times are those of kernels running alone.
