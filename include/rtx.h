@@ -150,7 +150,8 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "pool_factor"  retained shading nodes per batch pixel (default 4)
  *   "graphs"        1 (default): frames rendered through the _async entry points that need no host decision between
  *                   their launches (one batch, no reflective or transparent material, "kernel_timing" 0) are recorded once as a hipGraph
- *                   and replayed, which costs the host one call per frame instead of about ten; 0: always plain launches
+ *                   and replayed, which costs the host one call per frame instead of about ten (one recording per frame size, output
+ *                   buffer and in-flight slot; at most 32 are kept, so cycle through a few output buffers, not many); 0: always plain launches
  *   "kernel_timing" 1 (default): the traversal launches carry timing events (closest_ms, shadow_ms of the statistics);
  *                   0: no events, a frame's launches follow each other a few microseconds closer
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
