@@ -264,6 +264,31 @@ def test_recorded_frames_replay_exactly(big, rtx):
         ctx.set_option("kernel_timing", 1)
 
 
+def test_assemble_tiles_async_is_ordered_on_the_library_stream(big, rtx):
+    """rtx_assemble_tiles_async returns after enqueueing on rtx_stream: an event recorded on that stream
+    afterwards orders a reader on another stream, and the image equals the synchronous assembly's."""
+    import torch
+    _, ctx = big
+    w, h, world = 333, 77, 3
+    tpr = rtx.tiles_per_rank(w, h, world)
+    slabs = torch.zeros(world * tpr * 192, dtype=torch.uint8, device="cuda:0")
+    for r in range(world):
+        ctx.render_tiles(w, h, 10, 10, r, world, slabs.data_ptr() + r * tpr * 192)
+    ref = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    ctx.assemble_tiles(w, h, world, slabs.data_ptr(), ref.data_ptr())
+    img = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", 0))
+    ctx.assemble_tiles_async(w, h, world, slabs.data_ptr(), img.data_ptr())
+    done = torch.cuda.Event()
+    done.record(lib_stream)
+    torch.cuda.current_stream().wait_event(done)
+    same = torch.equal(img, ref)          # runs on torch's stream, after the event
+    torch.cuda.synchronize()
+    assert same
+    whole, _ = ctx.render(w, h, 10, 10)
+    assert np.array_equal(ref.cpu().numpy().reshape(h, w, 3), whole)
+
+
 def test_kernel_timing_option(big):
     """kernel_timing 0 drops the events on the traversal launches: same frame and counts,
     closest_ms / shadow_ms are reported as 0, the launch counts stay."""
