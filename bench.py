@@ -42,6 +42,26 @@ def cpu_baseline(flat, width, height, depth, samples, stride):
                       % (npix, stride, width, height, rays, st["seconds"])}
 
 
+def cpu_baseline_bvh(flat, width, height, depth, samples, stride):
+    """The same oracle through its restatement of the reference's own `-b` path (median-split BVH,
+    src/scene/bvh.rs:88-143), one thread: what a user of the reference gets on a large scene. The
+    tree is built first (the reference builds it in Tree::init); frames differ slightly from the
+    exhaustive ones by the reference's tie rule (bvh.rs:134), which does not matter for a rate."""
+    from oracle import oracle_ffi
+    oracle_ffi.build()
+    scene = oracle_ffi.OracleScene.from_flat(flat)
+    t0 = time.perf_counter()
+    out = scene.render(width, height, depth, samples, stride=(stride, stride), threads=1, use_bvh=True)
+    wall = time.perf_counter() - t0
+    st = out["stats"]
+    rays = st["primary_rays"] + st["shadow_rays"] + st["reflect_rays"] + st["refract_rays"]
+    npix = len(range(0, width, stride)) * len(range(0, height, stride))
+    return {"value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "tree_build_s": max(wall - st["seconds"], 0.0),
+            "sample": "%d pixels (every %dth in x and y) of the %dx%d frame, %d rays, %.2f s after a %.1f s tree build; the "
+                      "reference's median-split BVH" % (npix, stride, width, height, rays, st["seconds"], max(wall - st["seconds"], 0.0))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +400,11 @@ def main():
                 out["supplementary"] = {"error": str(e)}
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, w, h, args.depth, 10, args.cpu_stride)
+            if default_workload:     # about half a minute, most of it the tree build
+                try:
+                    out["cpu_baseline_bvh"] = cpu_baseline_bvh(flat, w, h, args.depth, 10, 4)
+                except Exception as e:
+                    out["cpu_baseline_bvh"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
