@@ -188,10 +188,11 @@ def main():
     # slab k is read by all-gather k and rewritten by render k + ring; gathered k is written by all-gather k,
     # read by assembly k and rewritten by all-gather k + ring.
     lib_streams = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs] if (multi and not gloo) else None
-    TIMED_EVERY = 8
+    TIMED_EVERY = 16
     timing_state = [1] * len(ctxs)
     gather_done = [None] * ring      # recorded on torch's stream once all-gather k has been waited for there
     assemble_done = [None] * ring    # recorded on the first context's stream after assembly k
+    event_pool = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(ring)] if (multi and not gloo) else None
 
     def finish_gather():
         if state["gather"] is None:
@@ -200,12 +201,12 @@ def main():
         state["gather"] = None
         t_w = time.perf_counter()
         work.wait()                                     # torch's current stream waits for the collective
-        ev = torch.cuda.Event()
+        ev = event_pool[idx][0]
         ev.record()
         gather_done[idx] = ev
         lib_streams[0].wait_event(ev)                   # ... and so does the stream that assembles
         ctx.assemble_tiles_async(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
-        ev2 = torch.cuda.Event()
+        ev2 = event_pool[idx][1]
         ev2.record(lib_streams[0])
         assemble_done[idx] = ev2
         gather_wait[0] += time.perf_counter() - t_w
