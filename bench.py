@@ -5,9 +5,10 @@ Workload (BASELINE.json configs[2], the largest single-GPU configuration): synth
 1 002 528-triangle tessellated height field + 4 point lights at 1920x1080, depth 10
 (the reference's default; the scene has no reflective or refractive material, so one
 level of rays is traced: primary + 4 shadow rays per hit). One step = one frame, scene
-and BVH resident in HBM. N > 1: the frame is sharded by interleaved 8x8 tiles, the
-scene is broadcast once from rank 0 over RCCL and every step ends with an all-gather of
-the tile slabs (strong scaling: the frame is fixed).
+and BVH resident in HBM; frames are pipelined (the next frame is enqueued while the last
+one is collected) and all of them are complete before the clock stops. N > 1: the frame is
+sharded by interleaved 8x8 tiles, the scene is broadcast once from rank 0 over RCCL and
+every frame's tile slabs are all-gathered and assembled (strong scaling: the frame is fixed).
 
 Prints ONE JSON line on rank 0.
 """
