@@ -189,6 +189,19 @@ int rtx_intersect_batch(rtx_context* ctx, uint64_t n, const float* ori3, const f
  * the kernel has been enqueued and synchronised. */
 int rtx_intersect_batch_device(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
                                int32_t* d_prim_id, float* d_t);
+/* No counterpart in the reference. For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the query of
+ * rtx_intersect_batch_device with the overflow area of the per-lane traversal stacks in a static
+ * device array of the library (24 MiB per GPU, held until the process ends) instead of the context's
+ * own allocation. The call allocates and frees nothing and does not synchronise: the kernel is
+ * enqueued on the context's stream (rtx_stream) and the caller waits for it there. Limits, rejected
+ * with RTX_ERR_UNSUPPORTED: n <= RTX_NOALLOC_MAX_RAYS per call, and a tree whose traversal needs at
+ * most 48 stack entries beyond the 16 kept in LDS (about 20 levels of 4-wide nodes; every bundled and
+ * synthetic scene up to 64 M primitives fits). All calls on one GPU share the array: calls that
+ * overlap on one GPU (two contexts or streams) race; calls that follow each other need no clearing. */
+#define RTX_NOALLOC_MAX_RAYS (1ull << 26)
+int rtx_intersect_batch_device_noalloc(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                                       int32_t* d_prim_id, float* d_t);
 /* Same query through the exhaustive device kernel regardless of scene size
  * (the device restatement of the loop at src/scene/mod.rs:186-199). */
 int rtx_intersect_batch_exhaustive(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3,

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
+    "rtx_intersect_batch_device_noalloc",
 ]
 
 
@@ -137,6 +138,7 @@ def lib():
         L.rtx_intersect_batch.argtypes = [vp, u64, vp, vp, vp, vp]
         L.rtx_intersect_batch_device.argtypes = [vp, u64, vp, vp, vp, vp]
         L.rtx_intersect_batch_exhaustive.argtypes = [vp, u64, vp, vp, vp, vp]
+        L.rtx_intersect_batch_device_noalloc.argtypes = [vp, u64, vp, vp, vp, vp]
         L.rtx_primary_hits.argtypes = [vp, u32, u32, vp, vp, vp]
         L.rtx_render.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(RenderStats)]
         L.rtx_render_device.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(RenderStats)]
@@ -353,6 +355,11 @@ class Context:
     def intersect_batch_device(self, d_ori, d_dir, d_prim, d_t, n):
         """Device pointers (ints), e.g. torch tensors' data_ptr()."""
         self._check(self._L.rtx_intersect_batch_device(self._h, int(n), d_ori, d_dir, d_prim, d_t))
+
+    def intersect_batch_device_noalloc(self, d_ori, d_dir, d_prim, d_t, n):
+        """Enqueue-only variant that allocates nothing (see rtx_intersect_batch_device_noalloc): the caller
+        synchronises the context's stream (stream()) or the device before reading the outputs."""
+        self._check(self._L.rtx_intersect_batch_device_noalloc(self._h, int(n), d_ori, d_dir, d_prim, d_t))
 
     def primary_hits(self, width, height):
         prim = np.empty((height, width), np.int32)

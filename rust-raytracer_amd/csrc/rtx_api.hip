@@ -81,6 +81,15 @@ int rtx_create(int device, rtx_context** out_ctx) {
         delete ctx;
         return rtx_fail(nullptr, RTX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    {   // address of this device's copy of the static scratch array (rtx_intersect_batch_device_noalloc)
+        std::string err;
+        const int rc = rtx_noalloc_init_device(device, &err);
+        if (rc != RTX_OK) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return rtx_fail(nullptr, rc, err);
+        }
+    }
     *out_ctx = ctx;
     return RTX_OK;
 }
@@ -284,6 +293,14 @@ int rtx_intersect_batch_device(rtx_context* ctx, uint64_t n, const float* d_ori3
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTX_OK;
+}
+
+int rtx_intersect_batch_device_noalloc(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                                       int32_t* d_prim_id, float* d_t) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (n && (!d_ori3 || !d_dir3 || !d_prim_id)) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "NULL ray or output pointer");
+    return rtx_launch_intersect_noalloc(ctx, n, d_ori3, d_dir3, d_prim_id, d_t);
 }
 
 static int intersect_host(rtx_context* ctx, uint64_t n, const float* ori3, const float* dir3, int32_t* prim_id, float* t, int mode) {

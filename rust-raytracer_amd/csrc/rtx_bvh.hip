@@ -819,7 +819,8 @@ int rtx_bvh_build(rtx_context* ctx) {
     // top 8 * RTX_MAX_DEPTH entries hold the suspended calls of a shadow ray's recursion.
     {
         const uint32_t need = 3 * (levels4 + 1) + 4;   // levels4: height of the 4-wide tree (0 without a BVH)
-        s.spill_entries = (need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0) + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
+        ctx->trav_spill_need = need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0;
+        s.spill_entries = ctx->trav_spill_need + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
         s.spill_stride = ctx->num_cus * 8 * 256;
         int* spill = nullptr;
         TRY(dev_alloc(ctx, ctx->build_allocs, &spill, (size_t)s.spill_entries * s.spill_stride));

@@ -141,6 +141,7 @@ struct rtx_context {
     size_t build_arena_size = 0;
     bool hit_fraction_known = false;   // a frame of the current scene has been collected
     float hit_fraction = 1.0f;   // share of the last frame's closest-hit rays that hit something
+    uint32_t trav_spill_need = 0;   // stack entries beyond the LDS part that a traversal of the built tree can need
     int64_t opt_stamps = 0;
 
     // Frames in flight (rtx_render_*_async / rtx_render_wait): a frame whose kernels need no host
@@ -189,6 +190,9 @@ int rtx_bvh_build(rtx_context* ctx);
 // rtx_trace.hip
 int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
                          int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);
+int rtx_noalloc_init_device(int device, std::string* err);   // once per device, with that device current (rtx_create)
+int rtx_launch_intersect_noalloc(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
+                                 int32_t* d_prim, float* d_t);
 // rtx_shade.hip
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
                     uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct,
