@@ -37,11 +37,13 @@ typedef enum rtx_status {
     RTX_ERR_HIP = 3,           /* a HIP runtime call failed; see rtx_last_error */
     RTX_ERR_NO_SCENE = 4,      /* render/intersect before rtx_scene_set (reference: panic, src/lib.rs:72,275) */
     RTX_ERR_NOT_BUILT = 5,     /* render/intersect before rtx_build */
-    RTX_ERR_UNSUPPORTED = 6,   /* e.g. depth above RTX_MAX_DEPTH, area lights */
+    RTX_ERR_UNSUPPORTED = 6,   /* e.g. a depth above RTX_MAX_DEPTH that the scene would really use, more than 2^28 primitives */
     RTX_ERR_OUT_OF_MEMORY = 7
 } rtx_status;
 
-#define RTX_MAX_DEPTH 32u             /* recursion depth accepted by rtx_render* */
+/* Deepest recursion rtx_render* follows. The reference takes any usize (src/main.rs:65); a larger depth is
+ * accepted (and changes nothing) when no material reflects or refracts, and rejected otherwise. */
+#define RTX_MAX_DEPTH 32u
 #define RTX_MATERIAL_NONE 0xFFFFFFFFu /* absent slot of a poly's material list */
 
 /* Material: src/scene/material.rs:86-94. 14 f32 = 56 bytes. Colours are already
@@ -170,6 +172,17 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
  * to the device. The camera basis of setup_camera (src/lib.rs:69-84) is
  * computed per frame because it depends on width/height. */
 int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* scene);
+/* Same, for a scene whose triangle and sphere arrays (tri_*, sph_*) already live in DEVICE memory of the
+ * context's GPU -- e.g. the receive buffers of an RCCL broadcast -- so that a replicated scene does not travel
+ * GPU -> host -> GPU on every rank. `materials` and `lights` stay HOST arrays (they are small and the host reads
+ * them). The arrays are copied device-to-device on the context's stream; the caller keeps ownership. A rejected
+ * descriptor (either call) leaves the context's previous scene in place. No counterpart in the reference. */
+int rtx_scene_set_device(rtx_context* ctx, const rtx_scene_desc* scene);
+/* A second context on the same GPU that SHARES the scene arrays and the built tree of `src` (reference-counted,
+ * read-only) and has its own stream, render workspace and traversal scratch: frames of several such contexts
+ * overlap on the GPU without a second copy of the scene or a second build. Options are copied. A later
+ * rtx_scene_set / rtx_build on either context only affects that context. No counterpart in the reference. */
+int rtx_clone(rtx_context* src, rtx_context** out_ctx);
 
 /* Replaces Tree::init (src/scene/bvh.rs:82-113), the reference's `-b` build:
  * bounds -> Morton keys -> LDS radix sort -> Karras hierarchy -> refit ->

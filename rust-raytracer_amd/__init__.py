@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
-    "rtx_intersect_batch_device_noalloc",
+    "rtx_intersect_batch_device_noalloc", "rtx_scene_set_device", "rtx_clone",
 ]
 
 
@@ -134,6 +134,8 @@ def lib():
         L.rtx_last_error.restype = C.c_char_p
         L.rtx_set_option.argtypes = [vp, C.c_char_p, i64]
         L.rtx_scene_set.argtypes = [vp, vp]
+        L.rtx_scene_set_device.argtypes = [vp, vp]
+        L.rtx_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtx_build.argtypes = [vp, C.POINTER(BuildStats)]
         L.rtx_intersect_batch.argtypes = [vp, u64, vp, vp, vp, vp]
         L.rtx_intersect_batch_device.argtypes = [vp, u64, vp, vp, vp, vp]
@@ -286,15 +288,26 @@ def parse_scene(path):
 class Context:
     """One rtx_context: a scene resident on one GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _handle=None):
         self._L = lib()
         h = C.c_void_p()
-        rc = self._L.rtx_create(int(device), C.byref(h))
-        if rc != RTX_OK:
-            raise RtxError(rc, self._L.rtx_last_error(None).decode())
+        if _handle is not None:
+            h = _handle
+        else:
+            rc = self._L.rtx_create(int(device), C.byref(h))
+            if rc != RTX_OK:
+                raise RtxError(rc, self._L.rtx_last_error(None).decode())
         self._h = h
         self.device = int(device)
         self.build_stats = None
+
+    def clone(self):
+        """A context on the same GPU sharing this one's scene and tree (rtx_clone): own stream and workspace."""
+        h = C.c_void_p()
+        self._check(self._L.rtx_clone(self._h, C.byref(h)))
+        c = Context(self.device, _handle=h)
+        c.build_stats = dict(self.build_stats) if self.build_stats else None
+        return c
 
     def close(self):
         if getattr(self, "_h", None):
@@ -323,6 +336,23 @@ class Context:
     def set_scene(self, flat):
         d, keep = flat.desc()
         self._check(self._L.rtx_scene_set(self._h, C.cast(C.byref(d), C.c_void_p)))
+
+    def set_scene_device(self, meta, tensors):
+        """Scene whose triangle / sphere arrays are device tensors (rtx_scene_set_device), e.g. the receive buffers of
+        a broadcast. `meta`: dict with n_tris, n_spheres, materials and lights (numpy, host) and camera; `tensors` maps
+        array names (tri_pos, tri_normals, tri_mat, tri_flags, tri_prim_index, sph_center_radius, sph_mat,
+        sph_prim_index) to objects with data_ptr(), or None."""
+        mats = np.ascontiguousarray(meta["materials"])
+        lights = np.ascontiguousarray(meta["lights"])
+        d = SceneDesc()
+        d.n_tris, d.n_spheres = int(meta["n_tris"]), int(meta["n_spheres"])
+        for name in ("tri_pos", "tri_normals", "tri_mat", "tri_flags", "tri_prim_index", "sph_center_radius", "sph_mat", "sph_prim_index"):
+            t = tensors.get(name)
+            setattr(d, name, None if t is None else C.c_void_p(t.data_ptr()))
+        d.n_materials, d.materials = len(mats), _ptr(mats)
+        d.n_lights, d.lights = len(lights), _ptr(lights)
+        d.camera = meta["camera"]
+        self._check(self._L.rtx_scene_set_device(self._h, C.cast(C.byref(d), C.c_void_p)))
 
     def build(self):
         st = BuildStats()

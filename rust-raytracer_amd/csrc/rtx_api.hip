@@ -8,14 +8,15 @@
 namespace {
 thread_local std::string g_create_error;
 
+// Copies `count` elements into a fresh allocation owned by `store`; kind: where `src` lives.
 template <typename T>
-int upload(rtx_context* ctx, const T* host, size_t count, T** out) {
+int upload(rtx_context* ctx, DevStore& store, const T* src, size_t count, T** out, hipMemcpyKind kind = hipMemcpyHostToDevice) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
     if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, std::string("hipMalloc(scene): ") + hipGetErrorString(e));
-    ctx->scene_allocs.push_back(p);
-    if (count && host) {
-        e = hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    store.ptrs.push_back(p);
+    if (count && src) {
+        e = hipMemcpyAsync(p, src, count * sizeof(T), kind, ctx->stream);
         if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_HIP, std::string("hipMemcpy(scene): ") + hipGetErrorString(e));
     }
     *out = (T*)p;
@@ -27,16 +28,37 @@ void free_list(std::vector<void*>& v) {
     v.clear();
 }
 
-// Device scratch for the host-pointer query entry points.
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+// Staging for the entry points that take host buffers: carved out of one buffer of the context that
+// only grows, so repeated calls of the same size allocate nothing.
+struct Staging {
+    rtx_context* ctx;
+    size_t used = 0;
+    bool ok = true;
+    size_t sizes[4] = {0, 0, 0, 0};
+    int n = 0;
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+    void want(size_t bytes) { sizes[n++] = pad(std::max<size_t>(bytes, 1)); }
+    int reserve() {
+        size_t total = 0;
+        for (int k = 0; k < n; ++k) total += sizes[k];
+        if (ctx->io_size < total) {
+            if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->io_buf) (void)hipFree(ctx->io_buf);
+            ctx->io_buf = nullptr;
+            ctx->io_size = 0;
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, total);
+            if (e != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, std::string("hipMalloc(staging): ") + hipGetErrorString(e));
+            ctx->io_buf = p;
+            ctx->io_size = total;
+        }
+        return RTX_OK;
+    }
     template <typename T>
-    T* get(size_t count) {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return (T*)p;
+    T* get(int k) {
+        size_t off = 0;
+        for (int j = 0; j < k; ++j) off += sizes[j];
+        return (T*)((char*)ctx->io_buf + off);
     }
 };
 
@@ -99,9 +121,11 @@ void rtx_destroy(rtx_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rtx_clear_graphs(ctx);
-    free_list(ctx->scene_allocs);
-    free_list(ctx->build_allocs);
+    ctx->scene_store.reset();
+    ctx->build_store.reset();
+    free_list(ctx->trav_allocs);
     free_list(ctx->work_allocs);
+    if (ctx->io_buf) (void)hipFree(ctx->io_buf);
     if (ctx->build_arena) (void)hipFree(ctx->build_arena);
     for (auto& e : ctx->order_bufs) (void)hipFree(e.second);
     ctx->order_bufs.clear();
@@ -160,7 +184,10 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
     return RTX_OK;
 }
 
-int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
+// Shared by rtx_scene_set (host arrays) and rtx_scene_set_device (device arrays; materials and lights on the host).
+// Everything is validated and uploaded into a new store first; the context's previous scene is
+// replaced only when that has succeeded, so a rejected descriptor leaves it usable.
+static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device_arrays) {
     if (!ctx) return RTX_ERR_INVALID_ARG;
     if (!d) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor is NULL");
     const uint64_t n64 = (uint64_t)d->n_tris + d->n_spheres;
@@ -169,37 +196,35 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
     if ((d->n_tris && (!d->tri_pos || !d->tri_mat)) || (d->n_spheres && (!d->sph_center_radius || !d->sph_mat)) ||
         (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
         return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "scene descriptor has a NULL array with a non-zero count");
+    for (uint32_t i = 0; i < d->n_lights; ++i)
+        if (d->lights[i].type > RTX_LIGHT_DIRECTIONAL) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "unknown light type");
+
+    // host arrays: prim_ref (reference primitive id -> (kind, index)) is built and checked here;
+    // device arrays: a kernel does the same after the copy (rtx_build_prim_ref)
+    std::vector<uint32_t> ref;
+    bool need_normals = false;
+    if (!device_arrays) {
+        ref.assign(n, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < d->n_tris; ++i) {
+            const uint32_t id = d->tri_prim_index ? d->tri_prim_index[i] : i;
+            if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
+            ref[id] = i;
+        }
+        for (uint32_t i = 0; i < d->n_spheres; ++i) {
+            const uint32_t id = d->sph_prim_index ? d->sph_prim_index[i] : d->n_tris + i;
+            if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
+            ref[id] = i | 0x80000000u;
+        }
+        if (d->tri_flags)
+            for (uint32_t i = 0; i < d->n_tris && !need_normals; ++i) need_normals = (d->tri_flags[i] & RTX_TRI_VERTEX_NORMAL) != 0;
+        if (need_normals && !d->tri_normals) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a triangle has RTX_TRI_VERTEX_NORMAL but tri_normals is NULL");
+    }
     RTX_HIP(ctx, hipSetDevice(ctx->device));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old scene
-    rtx_clear_graphs(ctx);
-    ctx->hit_fraction = 1.0f;
-    ctx->hit_fraction_known = false;
-
-    // prim_ref: reference primitive id -> (kind, index); the id arrays must form a permutation.
-    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
-    for (uint32_t i = 0; i < d->n_tris; ++i) {
-        const uint32_t id = d->tri_prim_index ? d->tri_prim_index[i] : i;
-        if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
-        ref[id] = i;
-    }
-    for (uint32_t i = 0; i < d->n_spheres; ++i) {
-        const uint32_t id = d->sph_prim_index ? d->sph_prim_index[i] : d->n_tris + i;
-        if (id >= n || ref[id] != 0xFFFFFFFFu) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
-        ref[id] = i | 0x80000000u;
-    }
-    bool need_normals = false;
-    if (d->tri_flags)
-        for (uint32_t i = 0; i < d->n_tris && !need_normals; ++i) need_normals = (d->tri_flags[i] & RTX_TRI_VERTEX_NORMAL) != 0;
-    if (need_normals && !d->tri_normals) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a triangle has RTX_TRI_VERTEX_NORMAL but tri_normals is NULL");
-
-    free_list(ctx->scene_allocs);
-    free_list(ctx->build_allocs);
-    for (auto& e : ctx->order_bufs) (void)hipFree(e.second);   // unit costs of the previous scene
-    ctx->order_bufs.clear();
-    ctx->has_scene = false;
-    ctx->built = false;
     const auto t0 = std::chrono::steady_clock::now();
 
+    auto store = std::make_shared<DevStore>();
+    const hipMemcpyKind kind = device_arrays ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     DevScene s{};
     s.n_prims = n;
     s.n_tris = d->n_tris;
@@ -214,27 +239,34 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
     rtx_material* d_mats = nullptr;
     DevLight* d_lights = nullptr;
     int rc;
-#define S_TRY(x) do { rc = (x); if (rc != RTX_OK) { free_list(ctx->scene_allocs); return rc; } } while (0)
-    S_TRY(upload(ctx, ref.data(), n, &d_ref));
-    S_TRY(upload(ctx, d->tri_pos, (size_t)d->n_tris * 9, &d_pos));
-    if (need_normals) S_TRY(upload(ctx, d->tri_normals, (size_t)d->n_tris * 9, &d_nrm));
-    S_TRY(upload(ctx, d->tri_mat, (size_t)d->n_tris * 3, &d_tmat));
-    std::vector<uint8_t> zero_flags;
-    const uint8_t* flags = d->tri_flags;
-    if (!flags) {
-        zero_flags.assign(d->n_tris, 0);
-        flags = zero_flags.data();
+#define S_TRY(x) do { rc = (x); if (rc != RTX_OK) return rc; } while (0)
+    S_TRY(upload(ctx, *store, device_arrays ? (const uint32_t*)nullptr : ref.data(), n, &d_ref));
+    S_TRY(upload(ctx, *store, d->tri_pos, (size_t)d->n_tris * 9, &d_pos, kind));
+    S_TRY(upload(ctx, *store, d->tri_mat, (size_t)d->n_tris * 3, &d_tmat, kind));
+    S_TRY(upload(ctx, *store, d->tri_flags, (size_t)d->n_tris, &d_flags, kind));
+    if (!d->tri_flags) RTX_HIP(ctx, hipMemsetAsync(d_flags, 0, std::max<size_t>(d->n_tris, 1), ctx->stream));
+    S_TRY(upload(ctx, *store, (const float4*)d->sph_center_radius, (size_t)d->n_spheres, &d_sph, kind));
+    S_TRY(upload(ctx, *store, d->sph_mat, (size_t)d->n_spheres, &d_smat, kind));
+    S_TRY(upload(ctx, *store, d->materials, (size_t)d->n_materials, &d_mats));
+    if (device_arrays) {
+        uint32_t *d_ti = nullptr, *d_si = nullptr, *d_status = nullptr;
+        auto scratch_store = std::make_shared<DevStore>();   // index arrays are only needed to build prim_ref
+        if (d->tri_prim_index) S_TRY(upload(ctx, *scratch_store, d->tri_prim_index, (size_t)d->n_tris, &d_ti, kind));
+        if (d->sph_prim_index) S_TRY(upload(ctx, *scratch_store, d->sph_prim_index, (size_t)d->n_spheres, &d_si, kind));
+        S_TRY(upload(ctx, *scratch_store, (const uint32_t*)nullptr, 2, &d_status));
+        S_TRY(rtx_build_prim_ref(ctx, d->n_tris, d->n_spheres, d_ti, d_si, d_flags, d_ref, d_status));
+        uint32_t status[2] = {0, 0};
+        RTX_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+        RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (status[0]) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "prim_index arrays are not a permutation of 0..n-1");
+        need_normals = status[1] != 0;
+        if (need_normals && !d->tri_normals) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a triangle has RTX_TRI_VERTEX_NORMAL but tri_normals is NULL");
     }
-    S_TRY(upload(ctx, flags, (size_t)d->n_tris, &d_flags));
-    S_TRY(upload(ctx, (const float4*)d->sph_center_radius, (size_t)d->n_spheres, &d_sph));
-    S_TRY(upload(ctx, d->sph_mat, (size_t)d->n_spheres, &d_smat));
-    S_TRY(upload(ctx, d->materials, (size_t)d->n_materials, &d_mats));
+    if (need_normals) S_TRY(upload(ctx, *store, d->tri_normals, (size_t)d->n_tris * 9, &d_nrm, kind));
     std::vector<DevLight> lights(d->n_lights);
-    ctx->lights.assign(d->lights, d->lights + d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         DevLight l{};
         l.type = d->lights[i].type;
-        if (l.type > RTX_LIGHT_DIRECTIONAL) { free_list(ctx->scene_allocs); return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "unknown light type"); }
         for (int k = 0; k < 3; ++k) {
             l.a[k] = d->lights[i].a[k];
             l.b[k] = d->lights[i].b[k];
@@ -244,9 +276,21 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
         if (l.type == RTX_LIGHT_AREA) ++s.n_area_lights;
         lights[i] = l;
     }
-    S_TRY(upload(ctx, lights.data(), lights.size(), &d_lights));
+    S_TRY(upload(ctx, *store, lights.data(), lights.size(), &d_lights));
 #undef S_TRY
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope below
+
+    // the new scene is complete: it replaces the old one
+    rtx_clear_graphs(ctx);
+    ctx->hit_fraction = 1.0f;
+    ctx->hit_fraction_known = false;
+    ctx->scene_store = store;
+    ctx->build_store.reset();
+    free_list(ctx->trav_allocs);
+    for (auto& e : ctx->order_bufs) (void)hipFree(e.second);   // unit costs of the previous scene
+    ctx->order_bufs.clear();
+    ctx->built = false;
+    ctx->lights.assign(d->lights, d->lights + d->n_lights);
     ctx->has_secondary = false;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rtx_material& m = d->materials[i];
@@ -269,6 +313,51 @@ int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) {
     ctx->build_stats = rtx_build_stats{};
     ctx->build_stats.upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->has_scene = true;
+    return RTX_OK;
+}
+
+int rtx_scene_set(rtx_context* ctx, const rtx_scene_desc* d) { return scene_set_impl(ctx, d, false); }
+int rtx_scene_set_device(rtx_context* ctx, const rtx_scene_desc* d) { return scene_set_impl(ctx, d, true); }
+
+int rtx_clone(rtx_context* src, rtx_context** out_ctx) {
+    if (!out_ctx) return rtx_fail(src, RTX_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (!src) return RTX_ERR_INVALID_ARG;
+    if (!src->has_scene) return rtx_fail(src, RTX_ERR_NO_SCENE, "no scene has been set (rtx_scene_set)");
+    rtx_context* ctx = nullptr;
+    int rc = rtx_create(src->device, &ctx);
+    if (rc != RTX_OK) return rtx_fail(src, rc, rtx_last_error(nullptr));
+    ctx->camera = src->camera;
+    ctx->lights = src->lights;
+    ctx->ds = src->ds;
+    ctx->ds.spill = nullptr;     // per context: two streams must not share stack overflow slots
+    ctx->ds.stamps = nullptr;
+    ctx->build_stats = src->build_stats;
+    for (int k = 0; k < 3; ++k) { ctx->scene_min[k] = src->scene_min[k]; ctx->scene_max[k] = src->scene_max[k]; }
+    ctx->scene_store = src->scene_store;
+    ctx->build_store = src->build_store;
+    ctx->has_secondary = src->has_secondary;
+    ctx->has_scene = true;
+    ctx->opt_force_mode = src->opt_force_mode;
+    ctx->opt_batch_pixels = src->opt_batch_pixels;
+    ctx->opt_pool_factor = src->opt_pool_factor;
+    for (int k = 0; k < 4; ++k) ctx->opt_tune[k] = src->opt_tune[k];
+    ctx->opt_stamps = src->opt_stamps;
+    ctx->opt_graphs = src->opt_graphs;
+    ctx->opt_kernel_timing = src->opt_kernel_timing;
+    ctx->opt_cost_order = src->opt_cost_order;
+    ctx->trav_spill_need = src->trav_spill_need;
+    if (src->built) {
+        RTX_HIP(src, hipStreamSynchronize(src->stream));   // the tree the clone reads is complete
+        rc = rtx_alloc_traversal_scratch(ctx);
+        if (rc != RTX_OK) {
+            rtx_fail(src, rc, ctx->error);
+            rtx_destroy(ctx);
+            return rc;
+        }
+        ctx->built = true;
+    }
+    *out_ctx = ctx;
     return RTX_OK;
 }
 
@@ -308,12 +397,14 @@ static int intersect_host(rtx_context* ctx, uint64_t n, const float* ori3, const
     if (rc != RTX_OK) return rc;
     if (n == 0) return RTX_OK;
     if (!ori3 || !dir3 || !prim_id) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "NULL ray or output pointer");
-    Scratch sc;
-    float* d_o = sc.get<float>(n * 3);
-    float* d_d = sc.get<float>(n * 3);
-    int32_t* d_p = sc.get<int32_t>(n);
-    float* d_t = sc.get<float>(n);
-    if (!d_o || !d_d || !d_p || !d_t) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(ray batch) failed");
+    Staging sg{ctx};
+    sg.want(n * 12); sg.want(n * 12); sg.want(n * 4); sg.want(n * 4);
+    rc = sg.reserve();
+    if (rc != RTX_OK) return rc;
+    float* d_o = sg.get<float>(0);
+    float* d_d = sg.get<float>(1);
+    int32_t* d_p = sg.get<int32_t>(2);
+    float* d_t = sg.get<float>(3);
     RTX_HIP(ctx, hipMemcpyAsync(d_o, ori3, n * 12, hipMemcpyHostToDevice, ctx->stream));
     RTX_HIP(ctx, hipMemcpyAsync(d_d, dir3, n * 12, hipMemcpyHostToDevice, ctx->stream));
     rc = rtx_launch_intersect(ctx, n, d_o, d_d, d_p, d_t, mode);
@@ -336,11 +427,13 @@ int rtx_primary_hits(rtx_context* ctx, uint32_t width, uint32_t height, int32_t*
     if (rc != RTX_OK) return rc;
     if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
     const size_t np = (size_t)width * height;
-    Scratch sc;
-    int32_t* d_p = prim_id ? sc.get<int32_t>(np) : nullptr;
-    float* d_t = t ? sc.get<float>(np) : nullptr;
-    float* d_d = ray_dir ? sc.get<float>(np * 3) : nullptr;
-    if ((prim_id && !d_p) || (t && !d_t) || (ray_dir && !d_d)) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(hit map) failed");
+    Staging sg{ctx};
+    sg.want(np * 4); sg.want(np * 4); sg.want(np * 12);
+    rc = sg.reserve();
+    if (rc != RTX_OK) return rc;
+    int32_t* d_p = prim_id ? sg.get<int32_t>(0) : nullptr;
+    float* d_t = t ? sg.get<float>(1) : nullptr;
+    float* d_d = ray_dir ? sg.get<float>(2) : nullptr;
     rc = rtx_primary_impl(ctx, width, height, d_p, d_t, d_d);
     if (rc != RTX_OK) return rc;
     if (prim_id) RTX_HIP(ctx, hipMemcpy(prim_id, d_p, np * 4, hipMemcpyDeviceToHost));
@@ -417,9 +510,11 @@ int rtx_render(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t depth
     if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
     if (!rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rgb is NULL");
     const size_t img = (size_t)width * height * 3;
-    Scratch sc;
-    uint8_t* d_img = sc.get<uint8_t>(img);
-    if (!d_img) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc(framebuffer) failed");
+    Staging sg{ctx};
+    sg.want(img);
+    rc = sg.reserve();
+    if (rc != RTX_OK) return rc;
+    uint8_t* d_img = sg.get<uint8_t>(0);
     rc = rtx_render_impl(ctx, width, height, depth, samples, 0, 1, d_img, stats, true);
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemcpyAsync(rgb, d_img, img, hipMemcpyDeviceToHost, ctx->stream));

@@ -571,6 +571,33 @@ __global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32
     }
 }
 
+// prim_ref from device-resident index arrays (rtx_scene_set_device): ref[id] = element | kind bit, with the
+// permutation check of the host path: status[0] is raised when an id is out of range or taken twice
+// (ref starts as all ones; every id must be claimed exactly once, and n claims of n distinct ids fill the array),
+// status[1] when some triangle asks for vertex normals.
+__global__ __launch_bounds__(kThreads) void k_prim_ref(uint32_t n_tris, uint32_t n_spheres, const uint32_t* __restrict__ tri_index,
+                                                        const uint32_t* __restrict__ sph_index, const uint8_t* __restrict__ tri_flags,
+                                                        uint32_t* __restrict__ ref, uint32_t* __restrict__ status) {
+    const uint32_t n = n_tris + n_spheres;
+    bool bad = false, normals = false;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        uint32_t id, val;
+        if (i < n_tris) {
+            id = tri_index ? tri_index[i] : i;
+            val = i;
+            normals |= (tri_flags[i] & RTX_TRI_VERTEX_NORMAL) != 0;
+        } else {
+            const uint32_t k = i - n_tris;
+            id = sph_index ? sph_index[k] : n_tris + k;
+            val = k | 0x80000000u;
+        }
+        if (id >= n) bad = true;
+        else if (atomicExch(&ref[id], val) != 0xFFFFFFFFu) bad = true;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&status[0], 1u);
+    if (__ballot(normals) && (threadIdx.x & 63) == 0) atomicOr(&status[1], 1u);
+}
+
 template <typename T>
 int dev_alloc(rtx_context* ctx, std::vector<void*>& owner, T** out, size_t count) {
     void* p = nullptr;
@@ -605,21 +632,65 @@ inline uint32_t grid_for(uint64_t n, uint32_t cap = 4096) {
 
 }  // namespace
 
+int rtx_build_prim_ref(rtx_context* ctx, uint32_t n_tris, uint32_t n_spheres, const uint32_t* d_tri_index, const uint32_t* d_sph_index,
+                       const uint8_t* d_tri_flags, uint32_t* d_ref, uint32_t* d_status) {
+    const uint64_t n = (uint64_t)n_tris + n_spheres;
+    RTX_HIP(ctx, hipMemsetAsync(d_ref, 0xFF, std::max<uint64_t>(n, 1) * sizeof(uint32_t), ctx->stream));
+    RTX_HIP(ctx, hipMemsetAsync(d_status, 0, 2 * sizeof(uint32_t), ctx->stream));
+    if (n > 0)
+        hipLaunchKernelGGL(k_prim_ref, dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, n_tris, n_spheres, d_tri_index, d_sph_index,
+                           d_tri_flags, d_ref, d_status);
+    RTX_HIP(ctx, hipGetLastError());
+    return RTX_OK;
+}
+
+// Overflow area of the per-lane traversal stacks (see TravStack) and, when asked for, the stamp buffer: owned by the
+// context, not shared with clones. A 4-wide level pushes at most 3 entries; with transparent materials the top
+// 8 * RTX_MAX_DEPTH entries hold the suspended calls of a shadow ray's recursion.
+int rtx_alloc_traversal_scratch(rtx_context* ctx) {
+    DevScene& s = ctx->ds;
+    for (void* p : ctx->trav_allocs) (void)hipFree(p);
+    ctx->trav_allocs.clear();
+    s.spill_entries = ctx->trav_spill_need + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
+    s.spill_stride = ctx->num_cus * 8 * 256;
+    int* spill = nullptr;
+    int rc = dev_alloc(ctx, ctx->trav_allocs, &spill, (size_t)s.spill_entries * s.spill_stride);
+    if (rc != RTX_OK) return rc;
+    s.spill = spill;
+    s.stamps = nullptr;
+    if (ctx->opt_stamps) {
+        unsigned long long* stamps = nullptr;
+        const size_t count = (size_t)2 * (s.spill_stride / 64) * 4 + ((size_t)2 << 19);   // + per-unit records of diagnostic builds
+        rc = dev_alloc(ctx, ctx->trav_allocs, &stamps, count);
+        if (rc != RTX_OK) return rc;
+        RTX_HIP(ctx, hipMemsetAsync(stamps, 0, count * sizeof(unsigned long long), ctx->stream));
+        s.stamps = stamps;
+    }
+    return RTX_OK;
+}
+
 int rtx_bvh_build(rtx_context* ctx) {
     DevScene& s = ctx->ds;
     const uint32_t n = s.n_prims;
     hipStream_t st = ctx->stream;
-    for (void* p : ctx->build_allocs) (void)hipFree(p);
-    ctx->build_allocs.clear();
+    ctx->build_store.reset();      // a clone that shares the old tree keeps it alive
+    auto store = std::make_shared<DevStore>();
     ctx->built = false;
     rtx_build_stats bs{};
     bs.n_prims = n;
     bs.upload_ms = ctx->build_stats.upload_ms;
 
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     RTX_HIP(ctx, hipEventCreate(&ev0));
-    RTX_HIP(ctx, hipEventCreate(&ev1));
-    RTX_HIP(ctx, hipEventRecord(ev0, st));
+    if (hipEventCreate(&ev1) != hipSuccess) {
+        (void)hipEventDestroy(ev0);
+        return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
+    }
+    if (hipEventRecord(ev0, st) != hipSuccess) {
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        return rtx_fail(ctx, RTX_ERR_HIP, "hipEventRecord failed");
+    }
 
     // Temporaries come out of one arena (a dozen hipMalloc calls cost more than the kernels of a 1 M-primitive
     // build); it stays with the context for the next build unless it is large. What does not fit falls back to hipMalloc.
@@ -641,7 +712,10 @@ int rtx_bvh_build(rtx_context* ctx) {
         tmp.base = (char*)ctx->build_arena;
         tmp.size = ctx->build_arena_size;
     }
-    auto cleanup = [&]() {
+    auto cleanup = [&]() {   // every way out of the build, failures included
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        ev0 = ev1 = nullptr;
         for (void* p : tmp.extra) (void)hipFree(p);
         tmp.extra.clear();
         if (ctx->build_arena_size > ((size_t)1 << 30)) {   // do not sit on gigabytes between builds
@@ -655,7 +729,7 @@ int rtx_bvh_build(rtx_context* ctx) {
         return rtx_fail(ctx, RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
 
     PrimRec* recs = nullptr;
-    TRY(dev_alloc(ctx, ctx->build_allocs, &recs, (size_t)n + 1));   // one spare record: leaf fetches read 64 bytes (fetch_ref)
+    TRY(dev_alloc(ctx, store->ptrs, &recs, (size_t)n + 1));   // one spare record: leaf fetches read 64 bytes (fetch_ref)
     TRY_HIP(hipMemsetAsync(recs + n, 0, sizeof(PrimRec), st));
 
     // Scene bounds are needed in both modes (safe region of the padded tests).
@@ -779,7 +853,7 @@ int rtx_bvh_build(rtx_context* ctx) {
             if (round > 512) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
         }
         BvhNode* nodes = nullptr;
-        TRY(dev_alloc(ctx, ctx->build_allocs, &nodes, n - 1));
+        TRY(dev_alloc(ctx, store->ptrs, &nodes, n - 1));
         TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
         // Emission: one launch per level of the 4-wide tree, from the root down (the refit queues are free now).
         {
@@ -815,24 +889,10 @@ int rtx_bvh_build(rtx_context* ctx) {
         s.nodes = nodes;
         s.uses_bvh = 1;
     }
-    // Spill area of the per-lane traversal stacks (see TravStack): a 4-wide level pushes at most 3 entries; with transparent materials the
-    // top 8 * RTX_MAX_DEPTH entries hold the suspended calls of a shadow ray's recursion.
     {
         const uint32_t need = 3 * (levels4 + 1) + 4;   // levels4: height of the 4-wide tree (0 without a BVH)
         ctx->trav_spill_need = need > RTX_STACK_LDS ? need - RTX_STACK_LDS : 0;
-        s.spill_entries = ctx->trav_spill_need + (s.has_transparent ? 8 * RTX_MAX_DEPTH : 1);
-        s.spill_stride = ctx->num_cus * 8 * 256;
-        int* spill = nullptr;
-        TRY(dev_alloc(ctx, ctx->build_allocs, &spill, (size_t)s.spill_entries * s.spill_stride));
-        s.spill = spill;
-        s.stamps = nullptr;
-        if (ctx->opt_stamps) {
-            unsigned long long* stamps = nullptr;
-            const size_t count = (size_t)2 * (s.spill_stride / 64) * 4 + ((size_t)2 << 19);   // + per-unit records of diagnostic builds
-            TRY(dev_alloc(ctx, ctx->build_allocs, &stamps, count));
-            TRY_HIP(hipMemsetAsync(stamps, 0, count * sizeof(unsigned long long), st));
-            s.stamps = stamps;
-        }
+        TRY(rtx_alloc_traversal_scratch(ctx));
     }
     bs.uses_bvh = s.uses_bvh;
     TRY_HIP(hipEventRecord(ev1, st));
@@ -841,13 +901,12 @@ int rtx_bvh_build(rtx_context* ctx) {
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     bs.build_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     cleanup();
 #undef TRY
 #undef TRY_HIP
     if (s.uses_bvh && bs.max_depth > 200)
         return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows");
+    ctx->build_store = store;
     ctx->build_stats = bs;
     ctx->built = true;
     return RTX_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -104,6 +105,15 @@ struct RayQueue {
 #define RTX_RAY_VACUUM 1u
 #define RTX_RAY_VALID 2u
 
+// Device allocations that several contexts of one GPU may share (rtx_clone): the scene arrays and
+// the built tree. Freed when the last context holding them lets go.
+struct DevStore {
+    std::vector<void*> ptrs;
+    ~DevStore() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
 struct rtx_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -117,9 +127,14 @@ struct rtx_context {
     rtx_build_stats build_stats{};
     float scene_min[3]{}, scene_max[3]{};
 
-    // owned device allocations for the scene
-    std::vector<void*> scene_allocs;
-    std::vector<void*> build_allocs;
+    // device allocations: scene arrays and tree (shared with clones), traversal scratch of this context (stack overflow area, stamps)
+    std::shared_ptr<DevStore> scene_store;
+    std::shared_ptr<DevStore> build_store;
+    std::vector<void*> trav_allocs;
+    // staging for the entry points that take host buffers (rtx_render, rtx_intersect_batch*, rtx_primary_hits):
+    // one buffer that only grows, so calls of a steady size allocate nothing after the first
+    void* io_buf = nullptr;
+    size_t io_size = 0;
     // render workspace (grown on demand)
     std::vector<void*> work_allocs;
     uint64_t work_batch = 0;      // pixels per batch the workspace was sized for
@@ -187,6 +202,9 @@ int rtx_fail(rtx_context* ctx, int status, const std::string& msg);
 
 // rtx_bvh.hip
 int rtx_bvh_build(rtx_context* ctx);
+int rtx_alloc_traversal_scratch(rtx_context* ctx);   // this context's stack overflow area (and stamps) for the built tree
+int rtx_build_prim_ref(rtx_context* ctx, uint32_t n_tris, uint32_t n_spheres, const uint32_t* d_tri_index, const uint32_t* d_sph_index,
+                       const uint8_t* d_tri_flags, uint32_t* d_ref, uint32_t* d_status /*[2]: bad permutation, some vertex normal*/);
 // rtx_trace.hip
 int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
                          int32_t* d_prim, float* d_t, int mode /*0 auto,1 exhaustive,2 bvh*/);

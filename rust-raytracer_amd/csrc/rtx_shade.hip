@@ -13,6 +13,7 @@
 // Every count lives in device memory (Ctl); the host only reads the size of the
 // next queue once per level to stop early.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <utility>
@@ -999,11 +1000,24 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
 
 // Waits for the stream by polling: a blocking hipStreamSynchronize wakes up tens of
 // microseconds after the stream has drained, which is a large part of a sub-millisecond frame.
-inline hipError_t wait_stream(hipStream_t st) {
-    for (;;) {
-        const hipError_t e = hipStreamQuery(st);
+// The poll gives up after kWaitSeconds (a hung kernel must not pin a host core for ever): hipErrorNotReady is then
+// returned and reported as RTX_ERR_HIP by the caller.
+constexpr double kWaitSeconds = 300.0;
+template <typename Query>
+inline hipError_t poll_until_ready(Query query) {
+    std::chrono::steady_clock::time_point start;
+    for (uint64_t spins = 0;; ++spins) {
+        const hipError_t e = query();
         if (e != hipErrorNotReady) return e;
+        if ((spins & 0xfff) == 0xfff) {
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0xfff) start = now;
+            else if (std::chrono::duration<double>(now - start).count() > kWaitSeconds) return hipErrorNotReady;
+        }
     }
+}
+inline hipError_t wait_stream(hipStream_t st) {
+    return poll_until_ready([st]() { return hipStreamQuery(st); });
 }
 
 inline uint32_t blocks_for(uint64_t n, uint32_t cap) {
@@ -1151,7 +1165,13 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const DevScene& s = ctx->ds;
     rtx_context::AsyncSlot* slot = (async_slot >= 0) ? &ctx->async_slots[async_slot] : nullptr;
     hipStream_t st = ctx->stream;
-    if (depth > RTX_MAX_DEPTH) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "depth above RTX_MAX_DEPTH");
+    if (depth > RTX_MAX_DEPTH) {
+        // The reference accepts any depth (main.rs:65). Without a reflective or refractive material nothing recurses
+        // (one level of rays, lib.rs:230,241; shadow rays stop at the first hit, lib.rs:120-128), so the value is moot.
+        if (ctx->has_secondary || s.has_transparent)
+            return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "depth above RTX_MAX_DEPTH (32) for a scene with reflective or transparent materials");
+        depth = RTX_MAX_DEPTH;
+    }
     // num_samples only multiplies area-light rays (lib.rs:219-222)
     const uint32_t n_samples = s.n_area_lights ? std::max<uint32_t>(samples, 1) : 1;
     const uint64_t n_slots64 = (uint64_t)s.n_lights + (uint64_t)s.n_area_lights * (n_samples - 1);
@@ -1409,10 +1429,12 @@ int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats) {
     --ctx->async_count;
     slot.used = false;
     if (slot.deferred) {
-        for (;;) {   // poll the frame's own end event: a later frame may already be queued behind it
-            const hipError_t e = hipEventQuery(slot.f1);
-            if (e == hipSuccess) break;
-            if (e != hipErrorNotReady) return rtx_fail(ctx, RTX_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        {   // poll the frame's own end event: a later frame may already be queued behind it
+            hipEvent_t done = slot.f1;
+            const hipError_t e = poll_until_ready([done]() { return hipEventQuery(done); });
+            if (e != hipSuccess)
+                return rtx_fail(ctx, RTX_ERR_HIP, e == hipErrorNotReady ? std::string("the frame did not finish within the wait limit")
+                                                                         : std::string("hipEventQuery: ") + hipGetErrorString(e));
         }
         const Ctl* hc = (const Ctl*)((char*)ctx->pinned + (size_t)(2 + idx) * 4096);
         if (hc->overflow)   // rare: the frame's ray tree outgrew the queues; render it again the patient way

@@ -49,11 +49,15 @@ def assemble(slabs, width, height, world):
     return img[:height, :width].copy()
 
 
-def broadcast_scene(flat, src=0, device="cpu"):
+def broadcast_scene(flat, src=0, device="cpu", timing=None):
     """Replicates a FlatScene from rank `src` to every rank. `flat` may be None on
-    the other ranks. Arrays travel as byte tensors on `device`."""
+    the other ranks. Arrays travel as byte tensors on `device`. `timing` (a dict) receives
+    "collective_ms": the time inside the broadcast collectives alone (device-synchronised)."""
+    import time
     import torch
     import torch.distributed as dist
+    spent = [0.0]
+    on_gpu = str(device).startswith("cuda")
     rank = dist.get_rank()
     header = [None]
     if rank == src:
@@ -70,14 +74,21 @@ def broadcast_scene(flat, src=0, device="cpu"):
     out = flat if rank == src else _pkg.FlatScene()
 
     def bcast(arr, nbytes):
+        """Returns the array's bytes as a uint8 numpy array (a view of one host buffer, no further copies)."""
         if nbytes == 0:
-            return b""
+            return np.zeros((0,), np.uint8)
         if rank == src:
-            t = torch.frombuffer(bytearray(arr.tobytes()), dtype=torch.uint8).to(device)
+            t = torch.from_numpy(arr.reshape(-1).view(np.uint8)).to(device)     # one host->device copy, no staging copies
         else:
             t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
         dist.broadcast(t, src=src)
-        return t.cpu().numpy().tobytes()
+        if on_gpu:
+            torch.cuda.synchronize()
+        spent[0] += time.perf_counter() - t0
+        return arr.reshape(-1).view(np.uint8) if rank == src else t.cpu().numpy()
 
     for name, dt in _ARRAYS:
         shape = meta[name]
@@ -89,12 +100,64 @@ def broadcast_scene(flat, src=0, device="cpu"):
         src_arr = np.ascontiguousarray(getattr(flat, name), dt) if rank == src else None
         raw = bcast(src_arr, nbytes)
         if rank != src:
-            setattr(out, name, np.frombuffer(raw, dtype=dt).reshape(shape).copy())
+            setattr(out, name, raw.view(dt).reshape(shape))
     raw = bcast(np.ascontiguousarray(flat.materials) if rank == src else None, meta["n_materials"] * _pkg.MATERIAL_DTYPE.itemsize)
     if rank != src:
-        out.materials = np.frombuffer(raw, dtype=_pkg.MATERIAL_DTYPE).copy()
+        out.materials = raw.view(_pkg.MATERIAL_DTYPE)
     raw = bcast(np.ascontiguousarray(flat.lights) if rank == src else None, meta["n_lights"] * _pkg.LIGHT_DTYPE.itemsize)
     if rank != src:
-        out.lights = np.frombuffer(raw, dtype=_pkg.LIGHT_DTYPE).copy()
+        out.lights = raw.view(_pkg.LIGHT_DTYPE)
         out.camera = _pkg.Camera.from_buffer_copy(meta["camera"])
+    if timing is not None:
+        timing["collective_ms"] = spent[0] * 1e3
     return out
+
+
+def broadcast_scene_device(flat, src, device, timing=None):
+    """Replicates a scene from rank `src` into DEVICE memory of every rank: the triangle and sphere arrays are
+    broadcast as device tensors and stay there (hand them to Context.set_scene_device), so a replicated scene crosses
+    PCIe once, on the source rank only. Returns (meta, tensors): meta = counts, materials, lights (host numpy) and
+    camera; tensors = {array name: uint8 device tensor or None}. `timing["collective_ms"]`: time inside the broadcasts."""
+    import time
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    header = [None]
+    if rank == src:
+        meta = {"shapes": {}}
+        for name, dt in _ARRAYS:
+            a = getattr(flat, name)
+            meta["shapes"][name] = None if a is None else tuple(np.asarray(a).shape)
+        meta["n_tris"], meta["n_spheres"] = flat.n_tris, flat.n_spheres
+        meta["materials"] = np.ascontiguousarray(flat.materials).tobytes()
+        meta["lights"] = np.ascontiguousarray(flat.lights).tobytes()
+        meta["camera"] = bytes(flat.camera)
+        header = [meta]
+    dist.broadcast_object_list(header, src=src)
+    meta = header[0]
+    spent = 0.0
+    tensors = {}
+    for name, dt in _ARRAYS:
+        shape = meta["shapes"][name]
+        nbytes = 0 if shape is None else int(np.prod(shape)) * np.dtype(dt).itemsize
+        if nbytes == 0:
+            tensors[name] = None
+            continue
+        if rank == src:
+            host = np.ascontiguousarray(getattr(flat, name), dt).reshape(-1).view(np.uint8)
+            t = torch.from_numpy(host).to(device)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(t, src=src)
+        torch.cuda.synchronize()
+        spent += time.perf_counter() - t0
+        tensors[name] = t
+    out = {"n_tris": meta["n_tris"], "n_spheres": meta["n_spheres"],
+           "materials": np.frombuffer(meta["materials"], dtype=_pkg.MATERIAL_DTYPE),
+           "lights": np.frombuffer(meta["lights"], dtype=_pkg.LIGHT_DTYPE),
+           "camera": _pkg.Camera.from_buffer_copy(meta["camera"])}
+    if timing is not None:
+        timing["collective_ms"] = spent * 1e3
+    return out, tensors
