@@ -47,7 +47,8 @@ constexpr unsigned long long kCoopMiss = ((unsigned long long)0x7f800000u << 32)
 // Closest (ANY = false): out_id = primitive id or -1, out_t = its t.
 // Any-hit (ANY = true):  out_id = 1 when some primitive occludes the light at distance dist_light
 //                        (dist_light < 0: any hit occludes), else 0.
-template <bool ANY>
+// SPH: the scene holds spheres (false: triangle-only code, see record_hit).
+template <bool ANY, bool SPH = true>
 RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_light, TravStack& st, CoopLds& L, int threshold,
                       float& out_t, int& out_id) {
     const int lane = threadIdx.x & 63;
@@ -58,9 +59,9 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
         if (!s.uses_bvh || !in_safe_region(s, o)) {   // every primitive, as the reference loop does
             if (ANY) {
                 for (uint32_t i = 0; i < s.n_prims; ++i)
-                    if (any_record(s.recs, i, o, d, dist_light)) { best_id = 1; break; }
+                    if (any_record<SPH>(s.recs, i, o, d, dist_light)) { best_id = 1; break; }
             } else {
-                for (uint32_t i = 0; i < s.n_prims; ++i) test_record(s.recs, i, o, d, best_t, best_id);
+                for (uint32_t i = 0; i < s.n_prims; ++i) test_record<SPH>(s.recs, i, o, d, best_t, best_id);
             }
         } else {
             cur = 0;
@@ -104,20 +105,20 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
             st.t_mem += c1 - c0;
 #endif
             if (cur >= 0) {
-                cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
+                cur = node4_step<!ANY, SPH>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
             } else {
                 const uint32_t leaf = ~(uint32_t)cur;
                 const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
                 if (ANY) {
-                    bool occ = any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
-                    for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record(s.recs, first + k, o, d, dist_light);
+                    bool occ = any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
+                    for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record<SPH>(s.recs, first + k, o, d, dist_light);
                     if (occ) {
                         best_id = 1;
                         sp = 0;
                     }
                 } else {
-                    test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
-                    for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, best_t, best_id);
+                    test_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
+                    for (uint32_t k = 1; k < cnt; ++k) test_record<SPH>(s.recs, first + k, o, d, best_t, best_id);
                 }
 #ifdef RTX_COUNT_STEPS
                 st.leaves += cnt;
@@ -210,13 +211,13 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                 st.t_mem += d2 - d1;
 #endif
                 if (cur >= 0) {
-                    cur = node4_step<!ANY>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
+                    cur = node4_step<!ANY, SPH>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
                 } else {
                     const uint32_t leaf = ~(uint32_t)cur;
                     const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
                     if (ANY) {
-                        bool occ = any_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
-                        for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record(s.recs, first + k, o, d, dist_light);
+                        bool occ = any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
+                        for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record<SPH>(s.recs, first + k, o, d, dist_light);
                         if (occ) {
                             __hip_atomic_store(&slot[owner], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             sp = bot;
@@ -226,8 +227,8 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                         int bi = (int)(uint32_t)key;
                         const float bt0 = bt;
                         const int bi0 = bi;
-                        test_quads(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, bt, bi);
-                        for (uint32_t k = 1; k < cnt; ++k) test_record(s.recs, first + k, o, d, bt, bi);
+                        test_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, bt, bi);
+                        for (uint32_t k = 1; k < cnt; ++k) test_record<SPH>(s.recs, first + k, o, d, bt, bi);
                         if (bt != bt0 || bi != bi0)
                             __hip_atomic_fetch_min(&slot[owner], ((unsigned long long)f2u(bt) << 32) | (uint32_t)bi, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -369,6 +369,7 @@ static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_sh
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
+template <bool SPH>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         }
         int id = -1;
         float t = 0.0f;
-        coop_trace<false>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
+        coop_trace<false, SPH>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
         const uint64_t hits = __ballot(i < n && id >= 0);
@@ -711,7 +712,7 @@ struct ShadowTask {
     }
 };
 
-template <bool ANY, bool AREA>
+template <bool ANY, bool AREA, bool SPH>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
@@ -742,11 +743,11 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
         int id;
         bool live = k < total && task.start((uint32_t)k, o, d, dl);
         if (ANY) {
-            coop_trace<true>(s, live, o, d, dl, st, coop, s.tune[0], t, id);
+            coop_trace<true, SPH>(s, live, o, d, dl, st, coop, s.tune[0], t, id);
             if (live) task.finish_any(id != 0);
         } else {
             while (__ballot(live)) {   // all lanes stay in the loop: the traversal is cooperative
-                coop_trace<false>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+                coop_trace<false, SPH>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
                 if (live) live = task.finish_closest(id, t, o, d);
             }
         }
@@ -1098,15 +1099,25 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
-    if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
-    else hipLaunchKernelGGL(k_trace_queue, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+    if (ctx->ds.n_spheres) {
+        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        else hipLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+    } else {
+        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        else hipLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+    }
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
 template <bool ANY, bool AREA>
 void launch_shadow_kernel(dim3 grid, hipStream_t st, hipEvent_t t0, hipEvent_t t1, const DevScene& s, const Work& wk, uint32_t depth,
                           uint32_t n_slots, UnitOrder* uo) {
-    if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
-    else hipLaunchKernelGGL((k_shadow<ANY, AREA>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
+    if (s.n_spheres) {
+        if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA, true>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+        else hipLaunchKernelGGL((k_shadow<ANY, AREA, true>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
+    } else {
+        if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA, false>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+        else hipLaunchKernelGGL((k_shadow<ANY, AREA, false>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
+    }
 }
 void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint64_t tasks_upper, uint32_t n_slots, bool any,
                    UnitOrder* uo, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {

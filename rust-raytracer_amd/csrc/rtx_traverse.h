@@ -30,21 +30,26 @@ RTX_D uint32_t f2u(float f) { return __float_as_uint(f); }
 RTX_D float u2f(uint32_t u) { return __uint_as_float(u); }
 
 // The primitive test of one record (already in registers); t is valid when true is returned.
+// SPH = false: the scene has no sphere, so the record is a triangle (traversal kernels are compiled for both cases:
+// a triangle-only scene pays neither the kind test nor, in the node step, the sphere widening).
+template <bool SPH = true>
 RTX_D bool record_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& t) {
-    if (f2u(q1.w) == 0u) return tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
+    if (!SPH || f2u(q1.w) == 0u) return tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
     return sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
 }
 // One candidate primitive against one ray; updates (best_t, best_id).
+template <bool SPH = true>
 RTX_D void test_quads(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& best_t, int& best_id) {
     const int id = (int)f2u(q0.w);
     float t;
-    if (record_hit(q0, q1, q2, o, d, t) && (t < best_t || (t == best_t && id < best_id))) {
+    if (record_hit<SPH>(q0, q1, q2, o, d, t) && (t < best_t || (t == best_t && id < best_id))) {
         best_t = t;
         best_id = id;
     }
 }
+template <bool SPH = true>
 RTX_D void test_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float& best_t, int& best_id) {
-    test_quads(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, best_t, best_id);
+    test_quads<SPH>(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, best_t, best_id);
 }
 
 // The loop of src/scene/mod.rs:186-199 over every record.
@@ -211,7 +216,7 @@ RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, u
 // Returns the next reference, or `done` when nothing is hit and the stack is empty.
 // The lane's stack holds entries [bot, sp): bot > 0 once the oldest entries were given away (rtx_coop.h).
 // SORT = false (any-hit queries): the order of the children does not matter, they are taken as stored.
-template <bool SORT = true>
+template <bool SORT = true, bool SPH = true>
 RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D, const RayBox& rb, V3 o, float limit,
                      TravStack& st, int& sp, int bot, int done) {
 #ifdef RTX_COUNT_STEPS
@@ -233,7 +238,9 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
     const float inf = __builtin_inff();
     float t[4];
     int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
-    if (meta >> 31) {   // spheres below: widen their children (see kSphereK)
+    // spheres below: widen their children (see kSphereK). The branch is taken by the whole wavefront or not at all
+    // (a vote), so that wavefronts away from any sphere skip the widening arithmetic instead of computing it masked.
+    if (SPH && __ballot((meta >> 31) != 0u) != 0ull) {
         const float dx = fmaxf(fabsf(ox - o.x), fabsf(__builtin_fmaf(255.0f, stx, ox) - o.x));
         const float dy = fmaxf(fabsf(oy - o.y), fabsf(__builtin_fmaf(255.0f, sty, oy) - o.y));
         const float dz = fmaxf(fabsf(oz - o.z), fabsf(__builtin_fmaf(255.0f, stz, oz) - o.z));
@@ -247,7 +254,7 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
             __builtin_memcpy(&hf, &hs, 2);
             const float rq = fminf((float)hf, 65504.0f);             // +inf (no sphere) -> finite, masked below
             const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
-            e[k] = kd2 * __builtin_amdgcn_rcpf(den) * ((hbits != 0x7c00u) ? 1.002f : 0.0f);
+            e[k] = ((meta >> 31) != 0u && hbits != 0x7c00u) ? kd2 * __builtin_amdgcn_rcpf(den) * 1.002f : 0.0f;
         }
         node4_slabs<true>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, e, t);
     } else {
@@ -332,10 +339,12 @@ RTX_D bool occluding_hit(V3 o, V3 d, float t, float dist_light) {
     const V3 p = o + vmult(d, t);                 // Intersection::point, intersection.rs:26-28
     return !(vdistance(o, p) > dist_light);       // lib.rs:123-127
 }
+template <bool SPH = true>
 RTX_D bool any_quads(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float dist_light) {
     float t;
-    return record_hit(q0, q1, q2, o, d, t) && occluding_hit(o, d, t, dist_light);
+    return record_hit<SPH>(q0, q1, q2, o, d, t) && occluding_hit(o, d, t, dist_light);
 }
+template <bool SPH = true>
 RTX_D bool any_record(const PrimRec* __restrict__ recs, uint32_t idx, V3 o, V3 d, float dist_light) {
-    return any_quads(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, dist_light);
+    return any_quads<SPH>(recs[idx].q0, recs[idx].q1, recs[idx].q2, o, d, dist_light);
 }

@@ -1,0 +1,140 @@
+// microbench.hip -- two measurements that decide how the traversal kernels are read:
+//   1. VALU issue: shader cycles per wave64 v_fma_f32 with 1, 2, 4 waves per SIMD (independent chains), which
+//      turns SQ_INSTS_VALU into a share of the SIMDs' issue capacity;
+//   2. dependent gathers: wave-iterations per microsecond and CU when every lane chases pointers through a
+//      table of 64-byte records (the BVH access pattern), for several fetch shapes: 4, 2 or 1 dwordx4 per lane,
+//      half of the lanes masked off, and four adjacent lanes sharing one record (one dwordx4 each).
+// Build: hipcc -O3 --offload-arch=gfx950 -o tools/microbench tools/microbench.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void k_valu(float* out, int iters, unsigned long long* cyc) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float b = 1.0001f, c = 0.5f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                         "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(b), "v"(c));
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+// mode 0: 4 x dwordx4 per lane (64 B record), 1: 2 x dwordx4, 2: 1 x dwordx4, 3: mode 0 with odd lanes idle,
+// 4: four adjacent lanes fetch the four quarters of ONE record (one dwordx4 each; 16 records per wave-instruction)
+// 5: mode 0 with the records of a wave's lanes adjacent in memory (coherent rays)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ table, uint32_t mask, int iters, uint32_t* out) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t idx = (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
+    if (MODE == 4) idx = (blockIdx.x * 64 + (threadIdx.x >> 2)) * 2654435761u;
+    uint32_t acc = 0;
+    const bool idle = (MODE == 3) && (lane & 1);
+    for (int i = 0; i < iters && !idle; ++i) {
+        uint32_t rec = idx & mask;
+        if (MODE == 5) rec = ((idx & mask) & ~63u) | lane;
+        const uint4* p = table + (size_t)rec * 4;
+        uint4 a, b = make_uint4(0, 0, 0, 0), c = b, d = b;
+        if (MODE == 0 || MODE == 3 || MODE == 5) {
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+        } else if (MODE == 1) {
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+        } else if (MODE == 2) {
+            asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p) : "memory");
+        } else {
+            const uint4* q = p + (lane & 3);
+            asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(q) : "memory");
+            // all four lanes of the quad continue with the same record: take the first quarter's word
+            a.x = __shfl(a.x, lane & ~3u);
+        }
+        acc += a.y ^ b.z ^ c.w ^ d.x;
+        idx = a.x * 2654435761u + (uint32_t)i;     // the next record depends on the data just fetched
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc + idx;
+}
+
+template <int MODE>
+int run_gather(const char* name, const uint4* table, uint32_t mask, int blocks_per_cu, int cus, uint32_t* out) {
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int grid = blocks_per_cu * cus;
+    hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(256), 0, 0, table, mask, 200, out);
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_gather<MODE>, dim3(grid), dim3(256), 0, 0, table, mask, iters, out);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_iters = (double)grid * 4 * iters;
+    printf("  %-46s %d WG/CU: %7.3f ms  %8.1f wave-iterations/us/CU  = one per %6.1f cycles at 2.4 GHz\n", name, blocks_per_cu, ms,
+           wave_iters / (ms * 1e3) / cus, 2400.0 * cus * ms * 1e3 / wave_iters);
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device: %s, %d CUs, clock %d kHz\n", prop.name, cus, prop.clockRate);
+    // ---- 1. VALU issue ----
+    float* out;
+    unsigned long long* cyc;
+    CHECK(hipMalloc(&out, (size_t)cus * 8 * 1024 * sizeof(float)));
+    CHECK(hipMalloc(&cyc, (size_t)cus * 8 * 16 * sizeof(unsigned long long)));
+    const int iters = 20000;
+    for (int threads : {256, 512, 1024}) {
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k_valu, dim3(cus), dim3(threads), 0, 0, out, iters, cyc);
+        CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)cus * threads / 64);
+        CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto v : h) sum += (double)v;
+        const double per_wave = sum / h.size() / ((double)iters * 64);
+        const int waves_per_simd = threads / 256;
+        printf("VALU: %d wave(s) per SIMD: %.2f cycles per v_fma_f32 per wave, %.2f cycles of the SIMD per wave-instruction\n", waves_per_simd,
+               per_wave, per_wave / waves_per_simd);
+    }
+    // ---- 2. dependent gathers ----
+    for (size_t mb : {24, 192, 2048}) {
+        const size_t recs = (mb << 20) / 64;
+        uint32_t mask = 1;
+        while ((size_t)mask * 2 <= recs) mask *= 2;
+        mask -= 1;
+        uint4* table;
+        CHECK(hipMalloc(&table, ((size_t)mask + 1) * 64));
+        std::vector<uint32_t> host(((size_t)mask + 1) * 16);
+        uint64_t z = 12345;
+        for (auto& v : host) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (uint32_t)(z >> 33); }
+        CHECK(hipMemcpy(table, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+        uint32_t* gout;
+        CHECK(hipMalloc(&gout, (size_t)cus * 8 * 256 * 4));
+        printf("table of %zu MiB (%u records of 64 B), random dependent fetches:\n", (((size_t)mask + 1) * 64) >> 20, mask + 1);
+        for (int wg : {1, 2, 4, 8}) {
+            if (run_gather<0>("4 x dwordx4 per lane (64 B)", table, mask, wg, cus, gout)) return 1;
+        }
+        if (run_gather<1>("2 x dwordx4 per lane (32 B)", table, mask, 4, cus, gout)) return 1;
+        if (run_gather<2>("1 x dwordx4 per lane (16 B)", table, mask, 4, cus, gout)) return 1;
+        if (run_gather<3>("4 x dwordx4, odd lanes idle", table, mask, 4, cus, gout)) return 1;
+        if (run_gather<4>("quad shares a record, 1 x dwordx4 per lane", table, mask, 4, cus, gout)) return 1;
+        if (run_gather<5>("4 x dwordx4, a wave's records adjacent", table, mask, 4, cus, gout)) return 1;
+        CHECK(hipFree(table));
+        CHECK(hipFree(gout));
+    }
+    return 0;
+}
