@@ -34,22 +34,57 @@ __global__ void k_valu(float* out, int iters, unsigned long long* cyc) {
 // mode 0: 4 x dwordx4 per lane (64 B record), 1: 2 x dwordx4, 2: 1 x dwordx4, 3: mode 0 with odd lanes idle,
 // 4: four adjacent lanes fetch the four quarters of ONE record (one dwordx4 each; 16 records per wave-instruction)
 // 5: mode 0 with the records of a wave's lanes adjacent in memory (coherent rays)
+// 6: every lane gets its own 64-byte record, fetched quad-cooperatively: load j brings, for each quad, the record of
+//    the quad's lane j (each lane one quarter), then a 4x4 transpose inside the quad (DPP) hands every lane its record
+// 7: mode 6 with the records of a wave's lanes adjacent in memory
+template <int CTRL>
+__device__ __forceinline__ uint32_t qperm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ void quad_exchange(uint32_t& ra, uint32_t& rb, bool upper) {
+    const uint32_t send = upper ? ra : rb;
+    const uint32_t recv = qperm<CTRL>(send);
+    if (upper) ra = recv; else rb = recv;
+}
+__device__ __forceinline__ void quad_fetch64(const void* rec, uint4& a, uint4& b, uint4& c, uint4& d) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t p = (uint64_t)rec;
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32), piece = (lane & 3u) << 4;
+    const uint64_t p0 = ((uint64_t)qperm<0x00>(hi) << 32) | (qperm<0x00>(lo) | piece);
+    const uint64_t p1 = ((uint64_t)qperm<0x55>(hi) << 32) | (qperm<0x55>(lo) | piece);
+    const uint64_t p2 = ((uint64_t)qperm<0xAA>(hi) << 32) | (qperm<0xAA>(lo) | piece);
+    const uint64_t p3 = ((uint64_t)qperm<0xFF>(hi) << 32) | (qperm<0xFF>(lo) | piece);
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    const bool b0 = lane & 1, b1 = lane & 2;
+    quad_exchange<0xB1>(a.x, b.x, b0); quad_exchange<0xB1>(a.y, b.y, b0); quad_exchange<0xB1>(a.z, b.z, b0); quad_exchange<0xB1>(a.w, b.w, b0);
+    quad_exchange<0xB1>(c.x, d.x, b0); quad_exchange<0xB1>(c.y, d.y, b0); quad_exchange<0xB1>(c.z, d.z, b0); quad_exchange<0xB1>(c.w, d.w, b0);
+    quad_exchange<0x4E>(a.x, c.x, b1); quad_exchange<0x4E>(a.y, c.y, b1); quad_exchange<0x4E>(a.z, c.z, b1); quad_exchange<0x4E>(a.w, c.w, b1);
+    quad_exchange<0x4E>(b.x, d.x, b1); quad_exchange<0x4E>(b.y, d.y, b1); quad_exchange<0x4E>(b.z, d.z, b1); quad_exchange<0x4E>(b.w, d.w, b1);
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ table, uint32_t mask, int iters, uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
     if (MODE == 4) idx = (blockIdx.x * 64 + (threadIdx.x >> 2)) * 2654435761u;
     uint32_t acc = 0;
+    bool wrong = false;
     const bool idle = (MODE == 3) && (lane & 1);
     for (int i = 0; i < iters && !idle; ++i) {
         uint32_t rec = idx & mask;
-        if (MODE == 5) rec = ((idx & mask) & ~63u) | lane;
+        if (MODE == 5 || MODE == 7) rec = ((idx & mask) & ~63u) | lane;
         const uint4* p = table + (size_t)rec * 4;
         uint4 a, b = make_uint4(0, 0, 0, 0), c = b, d = b;
         if (MODE == 0 || MODE == 3 || MODE == 5) {
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
                          "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+        } else if (MODE == 6 || MODE == 7) {
+            quad_fetch64(p, a, b, c, d);
+            // check: the record's 16 words are hash(rec * 16 + w); word 5 must be there after the transpose
+            if (b.y != (uint32_t)(((uint64_t)(rec * 16u + 5u) * 0x9E3779B97F4A7C15ull) >> 32)) wrong = true;
         } else if (MODE == 1) {
             asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
@@ -64,7 +99,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4* __restrict__ table,
         acc += a.y ^ b.z ^ c.w ^ d.x;
         idx = a.x * 2654435761u + (uint32_t)i;     // the next record depends on the data just fetched
     }
-    out[blockIdx.x * 256 + threadIdx.x] = acc + idx;
+    out[blockIdx.x * 256 + threadIdx.x] = wrong ? 0xDEADBEEFu : ((acc + idx) & 0x7fffffffu);
 }
 
 template <int MODE>
@@ -111,20 +146,19 @@ int main() {
                per_wave, per_wave / waves_per_simd);
     }
     // ---- 2. dependent gathers ----
-    for (size_t mb : {24, 192, 2048}) {
-        const size_t recs = (mb << 20) / 64;
+    for (size_t kb : {16, 1024, 24 * 1024, 192 * 1024, 2048 * 1024}) {
+        const size_t recs = (kb << 10) / 64;
         uint32_t mask = 1;
         while ((size_t)mask * 2 <= recs) mask *= 2;
         mask -= 1;
         uint4* table;
         CHECK(hipMalloc(&table, ((size_t)mask + 1) * 64));
         std::vector<uint32_t> host(((size_t)mask + 1) * 16);
-        uint64_t z = 12345;
-        for (auto& v : host) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (uint32_t)(z >> 33); }
+        for (size_t w = 0; w < host.size(); ++w) host[w] = (uint32_t)(((uint64_t)(uint32_t)w * 0x9E3779B97F4A7C15ull) >> 32);
         CHECK(hipMemcpy(table, host.data(), host.size() * 4, hipMemcpyHostToDevice));
         uint32_t* gout;
         CHECK(hipMalloc(&gout, (size_t)cus * 8 * 256 * 4));
-        printf("table of %zu MiB (%u records of 64 B), random dependent fetches:\n", (((size_t)mask + 1) * 64) >> 20, mask + 1);
+        printf("table of %zu KiB (%u records of 64 B), random dependent fetches:\n", (((size_t)mask + 1) * 64) >> 10, mask + 1);
         for (int wg : {1, 2, 4, 8}) {
             if (run_gather<0>("4 x dwordx4 per lane (64 B)", table, mask, wg, cus, gout)) return 1;
         }
@@ -133,6 +167,17 @@ int main() {
         if (run_gather<3>("4 x dwordx4, odd lanes idle", table, mask, 4, cus, gout)) return 1;
         if (run_gather<4>("quad shares a record, 1 x dwordx4 per lane", table, mask, 4, cus, gout)) return 1;
         if (run_gather<5>("4 x dwordx4, a wave's records adjacent", table, mask, 4, cus, gout)) return 1;
+        for (int wg : {2, 4, 6}) {
+            if (run_gather<6>("quad-cooperative 64 B per lane + transpose", table, mask, wg, cus, gout)) return 1;
+        }
+        if (run_gather<7>("quad-cooperative, a wave's records adjacent", table, mask, 4, cus, gout)) return 1;
+        {   // the transpose must hand every lane its own record
+            std::vector<uint32_t> h((size_t)cus * 4 * 256);
+            CHECK(hipMemcpy(h.data(), gout, h.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (auto v : h) bad += (v == 0xDEADBEEFu);
+            printf("  quad-cooperative transpose check: %zu of %zu lanes got a wrong record\n", bad, h.size());
+        }
         CHECK(hipFree(table));
         CHECK(hipFree(gout));
     }
