@@ -164,6 +164,8 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "tune3"         primitives per leaf (1..8, default 1; at the next rtx_build)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.
+ *   "verify_build"  1 = rtx_build recomputes, in a launch of its own, every inner node's box from its children's and fails
+ *                   (RTX_ERR_HIP) when one differs from what the one-launch bottom-up refit handed over (tests; default 0)
  *   "stamps"        1 = traversal kernels record per-wavefront time stamps (see rtx_debug_stamps); at the next rtx_build */
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
 

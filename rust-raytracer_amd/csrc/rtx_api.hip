@@ -168,6 +168,8 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
         ctx->opt_kernel_timing = value ? 1 : 0;
     } else if (k == "cost_order") {
         ctx->opt_cost_order = value ? 1 : 0;
+    } else if (k == "verify_build") {
+        ctx->opt_verify_build = value ? 1 : 0;
     } else if (k == "stamps") {
         ctx->opt_stamps = value ? 1 : 0;
         ctx->built = false;   // the stamp buffer is allocated by rtx_build
@@ -343,6 +345,7 @@ int rtx_clone(rtx_context* src, rtx_context** out_ctx) {
     ctx->opt_pool_factor = src->opt_pool_factor;
     for (int k = 0; k < 4; ++k) ctx->opt_tune[k] = src->opt_tune[k];
     ctx->opt_stamps = src->opt_stamps;
+    ctx->opt_verify_build = src->opt_verify_build;
     ctx->opt_graphs = src->opt_graphs;
     ctx->opt_kernel_timing = src->opt_kernel_timing;
     ctx->opt_cost_order = src->opt_cost_order;

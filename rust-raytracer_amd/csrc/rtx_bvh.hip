@@ -2,8 +2,9 @@
 // median-split tree (Tree::init / Tree::build, src/scene/bvh.rs:82-113):
 //   bounds (Shape::get_bbox: poly.rs:122-136, sphere.rs:45-52; centroid: shapes/mod.rs:40-42)
 //   -> Morton keys -> LSD radix sort staged through LDS -> Karras hierarchy
-//   -> bottom-up refit (one launch per tree level) -> 64-byte traversal nodes
-//   with small subtrees collapsed into leaves of a few primitives (tune3, default RTX_LEAF_MAX).
+//   -> bottom-up refit in one launch (arrival counters, agent-scope release / acquire) -> 64-byte traversal
+//   nodes emitted level by level into a dense array (level order), small subtrees collapsed into leaves of
+//   a few primitives (tune3, default RTX_LEAF_MAX).
 // Queries on the result return what the exhaustive loop returns (see
 // rtx_traverse.h); the reference BVH's own tie rule (bvh.rs:134) is not copied.
 #include <algorithm>
@@ -119,20 +120,30 @@ __device__ __forceinline__ uint64_t spread21(uint64_t x) {  // bit i -> bit 3i
     return x;
 }
 
-struct MortonParams {
-    float cmin[3];
-    float scale[3];   // cells per unit length (0 when the extent is 0)
-    float qmax;       // 2^bits - 1
-};
-
+// Morton keys of the box centroids. The grid spans the centroids' bounding box with ONE cell size for all three
+// axes (the largest extent spans the grid), so cells are cubes: a thin scene such as a height field is not stretched
+// along its thin axis, which would interleave splits that separate nothing a ray cares about. The bounds are read
+// from device memory (k_bounds of the same stream), so the host does not wait for them.
 __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                                                      MortonParams mp, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                      const SceneBounds* __restrict__ sb, int bits, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+    float cmin[3], max_ext = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t lo = sb->cmin[k], hi = sb->cmax[k];
+        cmin[k] = __uint_as_float(lo ^ ((lo >> 31) ? 0x80000000u : 0xFFFFFFFFu));     // inverse of enc_f32
+        const float mx = __uint_as_float(hi ^ ((hi >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        const float ext = mx - cmin[k];
+        if (ext < __builtin_inff() && ext > max_ext) max_ext = ext;                    // also skips NaN
+    }
+    const float qmax = (float)((1u << bits) - 1u);
+    const float scale = (max_ext > 0.0f) ? (float)(1u << bits) / max_ext : 0.0f;
     for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < n; id += gridDim.x * kThreads) {
         const float4 a = bmin[id], b = bmax[id];
         const float cx = a.x * 0.5f + b.x * 0.5f, cy = a.y * 0.5f + b.y * 0.5f, cz = a.z * 0.5f + b.z * 0.5f;
-        const float qx = fminf(fmaxf((cx - mp.cmin[0]) * mp.scale[0], 0.0f), mp.qmax);
-        const float qy = fminf(fmaxf((cy - mp.cmin[1]) * mp.scale[1], 0.0f), mp.qmax);
-        const float qz = fminf(fmaxf((cz - mp.cmin[2]) * mp.scale[2], 0.0f), mp.qmax);
+        const float qx = fminf(fmaxf((cx - cmin[0]) * scale, 0.0f), qmax);
+        const float qy = fminf(fmaxf((cy - cmin[1]) * scale, 0.0f), qmax);
+        const float qz = fminf(fmaxf((cz - cmin[2]) * scale, 0.0f), qmax);
         keys[id] = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
         vals[id] = id;
     }
@@ -301,17 +312,30 @@ __device__ __forceinline__ int kdelta(const uint64_t* __restrict__ keys, int n, 
 }
 // Everything hierarchy construction, refit and emission keep about one node of the binary tree, in one
 // 64-byte line: those kernels follow parent / child links, so a node's fields are wanted together.
-struct alignas(64) BuildNode {
-    float4 mn;              // padded box minimum; w = smallest sphere radius below (+inf: none)
-    float4 mx;              // padded box maximum
+struct alignas(32) BuildNode {
     int l, r;               // children (inner nodes)
     int first, last;        // range of sorted primitives (inner nodes)
     int parent;             // -1 for the root
     uint32_t counter;       // children that have reported during refit
-    uint32_t height;        // 0 for a leaf or a subtree that becomes one
-    uint32_t pad;
+    uint32_t pad[2];
 };
-static_assert(sizeof(BuildNode) == 64, "one line per node");
+static_assert(sizeof(BuildNode) == 32, "two nodes per 64-byte line");
+// The boxes live in an array of their own, two 16-byte quads per node: they are handed from one workgroup to another
+// INSIDE the refit launch, and only write-through stores and cache-bypassing loads ever touch their lines there.
+//   box[2 * node]     = padded box minimum; w = smallest sphere radius below (+inf: none)
+//   box[2 * node + 1] = padded box maximum; w = bits of the height: 0 for a leaf or a subtree that becomes one
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_through(float4* p, float4 v) {   // 16-byte write-through store (system scope)
+    const f32x4 r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ void load_through2(const float4* p, float4& a, float4& b) {   // two quads, past L1 and the local L2
+    f32x4 ra, rb;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(ra), "=&v"(rb) : "v"(p) : "memory");
+    a = make_float4(ra.x, ra.y, ra.z, ra.w);
+    b = make_float4(rb.x, rb.y, rb.z, rb.w);
+}
 
 // Node ids: internal i in [0, n-1) -> i ; leaf j in [0, n) -> (n-1) + j.
 __global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict__ keys, int n, BuildNode* __restrict__ bn) {
@@ -359,56 +383,85 @@ __device__ __forceinline__ uint32_t f16_bits_down(float r) {
     return (uint32_t)(r * 16777216.0f);   // subnormal f16: multiples of 2^-24, truncated
 }
 
-// Leaves: padded primitive boxes. Padding covers primitive tests that accept a
-// ray passing marginally outside the exact shape (f32 rounding in
-// Moeller-Trumbore). The sphere discriminant's cancellation error grows with the
-// distance between ray origin and centre; it is covered at traversal time from
-// the smallest sphere radius of each subtree, carried in BuildNode::mn.w (+inf: no sphere).
-__global__ __launch_bounds__(kThreads) void k_leaf_init(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
-                                                         const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                                                         BuildNode* __restrict__ bn, int* __restrict__ queue,
-                                                         uint32_t* __restrict__ qcount, PadParams pp) {
+// Refit, one launch. Every thread starts at a leaf -- the padded primitive box: padding covers primitive tests that
+// accept a ray passing marginally outside the exact shape (f32 rounding in Moeller-Trumbore); the sphere discriminant's
+// cancellation error grows with the distance between ray origin and centre and is covered at traversal time from the
+// smallest sphere radius of each subtree, carried in the box minimum's w (+inf: no sphere) -- and walks towards the root.
+// At every inner node the first child to arrive stops; the second one finds its sibling's box complete, forms the
+// union (BoundingBox +, shapes/mod.rs:86-104) and goes on. The two arrivals may run on different CUs and XCDs, whose
+// L1s and L2s do not see each other's plain stores: the boxes are stored write-through (sc0 sc1), the storing wavefront
+// waits for its stores (vmcnt(0)) before it counts its arrival with a device-scope atomic, and the wavefront whose
+// arrival came second loads the sibling's box with loads that bypass the caches (sc0 sc1). No cache is flushed or
+// invalidated on the way (agent-scope fences per step cost this launch a factor of five).
+// *root_height receives the height of the binary tree. rtx_set_option("verify_build") recomputes every box afterwards.
+__global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
+                                                     const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                                                     BuildNode* __restrict__ bn, float4* __restrict__ box, PadParams pp, int leaf_max,
+                                                     uint32_t* __restrict__ root_height) {
     const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t id = sorted_ids[j];
-    float4 a = bmin[id], b = bmax[id];
-    float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
-    float pad = pp.rel * m + 1e-30f;
-    const uint32_t ref = s.prim_ref[id];
-    float rmin = __builtin_inff();
-    if (ref >> 31) {
-        rmin = fabsf(s.sph[ref & 0x7fffffffu].w);
-        if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
+    const bool live = j < n;
+    int me = -1, cur = -1;
+    float4 mn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mx = mn;
+    uint32_t h = 0;
+    if (live) {
+        const uint32_t id = sorted_ids[j];
+        const float4 a = bmin[id], b = bmax[id];
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
+        const float pad = pp.rel * m + 1e-30f;
+        const uint32_t ref = s.prim_ref[id];
+        float rmin = __builtin_inff();
+        if (ref >> 31) {
+            rmin = fabsf(s.sph[ref & 0x7fffffffu].w);
+            if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
+        }
+        me = (int)((n - 1) + j);
+        mn = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
+        mx = make_float4(b.x + pad, b.y + pad, b.z + pad, __uint_as_float(0u));
+        store_through(&box[2 * (size_t)me], mn);
+        store_through(&box[2 * (size_t)me + 1], mx);
+        cur = (n > 1) ? bn[me].parent : -1;
     }
-    const uint32_t node = (n - 1) + j;
-    bn[node].mn = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
-    bn[node].mx = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
-    bn[node].height = 0;
-    if (n > 1) {
-        const int p = bn[node].parent;
-        if (atomicAdd(&bn[p].counter, 1u) == 1u) queue[atomicAdd(qcount, 1u)] = p;
+    // bounded by the tree height; every lane leaves the loop (first arrival, or the root)
+    while (__ballot(cur >= 0)) {
+        uint32_t old = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's boxes have reached memory before its arrivals count
+        if (cur >= 0) old = __hip_atomic_fetch_add(&bn[cur].counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool second = cur >= 0 && old == 1u;
+        if (!second) cur = -1;
+        if (second) {
+            const int l = bn[cur].l, r = bn[cur].r;     // written by the launch before this one
+            const int sib = (l == me) ? r : l;
+            float4 sa, sb;
+            load_through2(&box[2 * (size_t)sib], sa, sb);
+            mn = make_float4(fminf(mn.x, sa.x), fminf(mn.y, sa.y), fminf(mn.z, sa.z), fminf(mn.w, sa.w));
+            const int size = bn[cur].last - bn[cur].first + 1;
+            h = (size <= leaf_max) ? 0u : min(1u + max(h, __float_as_uint(sb.w)), 255u);
+            mx = make_float4(fmaxf(mx.x, sb.x), fmaxf(mx.y, sb.y), fmaxf(mx.z, sb.z), __uint_as_float(h));
+            store_through(&box[2 * (size_t)cur], mn);
+            store_through(&box[2 * (size_t)cur + 1], mx);
+            me = cur;
+            cur = bn[cur].parent;
+            if (cur < 0) *root_height = h;   // the root is complete
+        }
     }
 }
 
-// One tree level per launch: every node in `qin` has both children finished by
-// earlier launches, so their boxes are visible without in-kernel fences.
-__global__ __launch_bounds__(kThreads) void k_refit_pass(const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
-                                                          BuildNode* __restrict__ bn, int* __restrict__ qout,
-                                                          uint32_t* __restrict__ qout_count, int leaf_max, uint32_t* __restrict__ n_levels) {
-    const uint32_t cnt = *qin_count;
-    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the root find an empty queue
-    for (uint32_t k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += gridDim.x * kThreads) {
-        const int i = qin[k];
-        const int l = bn[i].l, r = bn[i].r;
-        const float4 la = bn[l].mn, lb = bn[l].mx, ra = bn[r].mn, rb = bn[r].mx;
-        bn[i].mn = make_float4(fminf(la.x, ra.x), fminf(la.y, ra.y), fminf(la.z, ra.z), fminf(la.w, ra.w));  // BoundingBox + , shapes/mod.rs:86-104
-        bn[i].mx = make_float4(fmaxf(lb.x, rb.x), fmaxf(lb.y, rb.y), fmaxf(lb.z, rb.z), 0.0f);
-        const int size = bn[i].last - bn[i].first + 1;
-        const int h = (size <= leaf_max) ? 0 : 1 + (int)max(bn[l].height, bn[r].height);
-        bn[i].height = (uint32_t)min(h, 255);
-        const int p = bn[i].parent;
-        if (p >= 0 && atomicAdd(&bn[p].counter, 1u) == 1u) qout[atomicAdd(qout_count, 1u)] = p;
-    }
+// Optional check of the refit's hand-overs (the "verify_build" option), in a launch of its own, where every box is
+// visible: each inner node's box and height are recomputed from its children's and compared bit for bit.
+__global__ __launch_bounds__(kThreads) void k_verify_refit(int n, const BuildNode* __restrict__ bn, const float4* __restrict__ box, int leaf_max,
+                                                            uint32_t* __restrict__ mismatches) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n - 1) return;
+    const int l = bn[i].l, r = bn[i].r;
+    const float4 la = box[2 * (size_t)l], lb = box[2 * (size_t)l + 1], ra = box[2 * (size_t)r], rb = box[2 * (size_t)r + 1];
+    const float4 a = box[2 * (size_t)i], b = box[2 * (size_t)i + 1];
+    const int size = bn[i].last - bn[i].first + 1;
+    const uint32_t h = (size <= leaf_max) ? 0u : min(1u + max(__float_as_uint(lb.w), __float_as_uint(rb.w)), 255u);
+    auto same = [](float x, float y) { return __float_as_uint(x) == __float_as_uint(y); };
+    const bool ok = same(a.x, fminf(la.x, ra.x)) && same(a.y, fminf(la.y, ra.y)) && same(a.z, fminf(la.z, ra.z)) && same(a.w, fminf(la.w, ra.w)) &&
+                    same(b.x, fmaxf(lb.x, rb.x)) && same(b.y, fmaxf(lb.y, rb.y)) && same(b.z, fmaxf(lb.z, rb.z)) && __float_as_uint(b.w) == h &&
+                    bn[i].counter == 2u;
+    if (!ok) atomicAdd(mismatches, 1u);
 }
 
 // Reference to binary node c as a child of a traversal node: a leaf (single primitive
@@ -438,112 +491,139 @@ __device__ __forceinline__ uint32_t step_exponent(float extent) {
 }
 
 // Emits the 4-wide traversal nodes, top down, one level of the 4-wide tree per launch. A
-// traversal node is rooted at a binary node i (and stored at nodes[i]); its children start
+// traversal node is rooted at a binary node i; its children start
 // as i's two children, and while there are fewer than four, the child with the largest
 // surface area that is still an inner node is replaced by its own two children -- the big
 // boxes are the ones a ray is most likely to enter, so opening them here saves a step there.
-// Children that remain inner nodes root the traversal nodes of the next level (qout).
+// Children that remain inner nodes root the traversal nodes of the next level.
+// Nodes are numbered in level order, densely: the k-th root of a level is node base(level) + k, base(level) = the
+// number of nodes of all levels above, so the array has exactly one slot per node and the top of the tree -- what
+// every ray reads -- is contiguous. A workgroup reserves the slots of all its children at the next level with one
+// atomic (a per-wavefront reservation on one counter serialises at ~90 per microsecond).
 // Child boxes are quantised to 8 bits per plane relative to the node's own box, rounded
 // outward and verified with the same fma the traversal uses, so a quantised box always
 // contains the padded box.
+struct LevelInfo {
+    uint32_t count;   // roots at this level (reserved by the level above)
+    uint32_t leaves;  // leaf references emitted by this level
+};
 __device__ __forceinline__ float half_area(const float4& mn, const float4& mx) {
     const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
     return dx * dy + dy * dz + dz * dx;
 }
-__global__ __launch_bounds__(kThreads) void k_emit4(int n, const int* __restrict__ qin, const uint32_t* __restrict__ qin_count,
-                                                     int* __restrict__ qout, uint32_t* __restrict__ qout_count,
-                                                     const BuildNode* __restrict__ bn, BvhNode* __restrict__ nodes,
-                                                     uint32_t* __restrict__ counts, int leaf_max, uint32_t* __restrict__ n_levels) {
-    __shared__ uint32_t s_nodes, s_leaves;
-    if (threadIdx.x == 0) s_nodes = s_leaves = 0;
+__global__ __launch_bounds__(kThreads) void k_emit4(int n, uint32_t level, const int* __restrict__ qin, int* __restrict__ qout,
+                                                     LevelInfo* __restrict__ lvl, const BuildNode* __restrict__ bn, const float4* __restrict__ box,
+                                                     BvhNode* __restrict__ nodes, int leaf_max) {
+    __shared__ uint32_t s_leaves, s_base, lds4[4];
+    if (threadIdx.x == 0) s_leaves = 0;
     __syncthreads();
-    uint32_t my_nodes = 0, my_leaves = 0;
-    const uint32_t cnt = *qin_count;
-    if (cnt && blockIdx.x == 0 && threadIdx.x == 0) ++*n_levels;   // launches past the last level find an empty queue
-    for (uint32_t slot = blockIdx.x * kThreads + threadIdx.x; slot < cnt; slot += gridDim.x * kThreads) {
-        const int i = qin[slot];
-        int ch[4] = {bn[i].l, bn[i].r, 0, 0};
-        int nc = 2;
-        while (nc < 4) {
-            int best = -1;
-            float best_area = -1.0f;
-            for (int k = 0; k < nc; ++k) {
-                if (!is_expandable(ch[k], n, bn, leaf_max)) continue;
-                const float a = half_area(bn[ch[k]].mn, bn[ch[k]].mx);
-                if (!(a <= best_area)) {   // also takes a NaN area rather than stopping early
-                    best = k;
-                    best_area = a;
-                }
-            }
-            if (best < 0) break;
-            const int c = ch[best];
-            ch[best] = bn[c].l;
-            ch[nc++] = bn[c].r;
-        }
-        const float4 bmn = bn[i].mn, bmx = bn[i].mx;
-        const float org[3] = {bmn.x, bmn.y, bmn.z};
-        const float ext[3] = {bmx.x - bmn.x, bmx.y - bmn.y, bmx.z - bmn.z};
-        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, eb[3];
-        float cmn[4][3], cmx[4][3];
-        uint32_t rcode[4] = {0x7c00u, 0x7c00u, 0x7c00u, 0x7c00u};   // smallest sphere radius per child, f16; +inf = none
-        bool spheres = false;
-        for (int k = 0; k < nc; ++k) {
-            const float4 a = bn[ch[k]].mn, b = bn[ch[k]].mx;
-            if (a.w < __builtin_inff()) {
-                rcode[k] = f16_bits_down(a.w);
-                spheres = true;
-            }
-            cmn[k][0] = a.x; cmn[k][1] = a.y; cmn[k][2] = a.z;
-            cmx[k][0] = b.x; cmx[k][1] = b.y; cmx[k][2] = b.z;
-        }
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            uint32_t e = step_exponent(ext[ax]);
-            for (;;) {   // raise the step until every child plane is representable (at most a few rounds)
-                const float step = __uint_as_float(e << 23);
-                bool ok = true;
-                uint32_t lo_pack = 0, hi_pack = 0;
+    uint32_t my_leaves = 0;
+    const uint32_t cnt = lvl[level].count;
+    // nodes of all levels above: their counts are final (their launches have ended)
+    uint32_t node_base = 0;
+    for (uint32_t k = 0; k < level; ++k) node_base += lvl[k].count;
+    const uint32_t next_base = node_base + cnt;
+    for (uint32_t slot0 = blockIdx.x * kThreads; slot0 < cnt; slot0 += gridDim.x * kThreads) {   // block-uniform trip count
+        const uint32_t slot = slot0 + threadIdx.x;
+        const bool live = slot < cnt;
+        int ch[4] = {0, 0, 0, 0};
+        int nc = 0;
+        uint32_t inner = 0;   // children that root a node of the next level
+        int i = 0;
+        if (live) {
+            i = qin[slot];
+            ch[0] = bn[i].l;
+            ch[1] = bn[i].r;
+            nc = 2;
+            while (nc < 4) {
+                int best = -1;
+                float best_area = -1.0f;
                 for (int k = 0; k < nc; ++k) {
-                    float lo = floorf((cmn[k][ax] - org[ax]) / step);
-                    lo = fminf(fmaxf(lo, 0.0f), 255.0f);
-                    while (lo > 0.0f && __builtin_fmaf(lo, step, org[ax]) > cmn[k][ax]) lo -= 1.0f;
-                    float hi = ceilf((cmx[k][ax] - org[ax]) / step);
-                    hi = fminf(fmaxf(hi, 0.0f), 255.0f);
-                    while (hi < 255.0f && __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) hi += 1.0f;
-                    if (__builtin_fmaf(lo, step, org[ax]) > cmn[k][ax] || __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) ok = false;
-                    lo_pack |= (uint32_t)lo << (8 * k);
-                    hi_pack |= (uint32_t)hi << (8 * k);
+                    if (!is_expandable(ch[k], n, bn, leaf_max)) continue;
+                    const float a = half_area(box[2 * (size_t)ch[k]], box[2 * (size_t)ch[k] + 1]);
+                    if (!(a <= best_area)) {   // also takes a NaN area rather than stopping early
+                        best = k;
+                        best_area = a;
+                    }
                 }
-                if (ok || e >= 254u) {
-                    qlo[ax] = lo_pack;
-                    qhi[ax] = hi_pack;
-                    eb[ax] = e;
-                    break;
-                }
-                ++e;
+                if (best < 0) break;
+                const int c = ch[best];
+                ch[best] = bn[c].l;
+                ch[nc++] = bn[c].r;
             }
+            for (int k = 0; k < nc; ++k) inner += is_expandable(ch[k], n, bn, leaf_max) ? 1u : 0u;
         }
-        int ref[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nc; ++k) {
-            ref[k] = child_ref(ch[k], n, bn, &my_leaves, leaf_max);
-            if (ref[k] >= 0) qout[atomicAdd(qout_count, 1u)] = ref[k];   // roots a node of the next level
+        uint32_t total;
+        const uint32_t offset = block_excl_scan(inner, lds4, &total);
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(&lvl[level + 1].count, total) : 0u;
+        __syncthreads();
+        uint32_t pos = s_base + offset;   // position of this thread's first inner child in the next level
+        if (live) {
+            const float4 bmn = box[2 * (size_t)i], bmx = box[2 * (size_t)i + 1];
+            const float org[3] = {bmn.x, bmn.y, bmn.z};
+            const float ext[3] = {bmx.x - bmn.x, bmx.y - bmn.y, bmx.z - bmn.z};
+            uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, eb[3];
+            float cmn[4][3], cmx[4][3];
+            uint32_t rcode[4] = {0x7c00u, 0x7c00u, 0x7c00u, 0x7c00u};   // smallest sphere radius per child, f16; +inf = none
+            bool spheres = false;
+            for (int k = 0; k < nc; ++k) {
+                const float4 a = box[2 * (size_t)ch[k]], b = box[2 * (size_t)ch[k] + 1];
+                if (a.w < __builtin_inff()) {
+                    rcode[k] = f16_bits_down(a.w);
+                    spheres = true;
+                }
+                cmn[k][0] = a.x; cmn[k][1] = a.y; cmn[k][2] = a.z;
+                cmx[k][0] = b.x; cmx[k][1] = b.y; cmx[k][2] = b.z;
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                uint32_t e = step_exponent(ext[ax]);
+                for (;;) {   // raise the step until every child plane is representable (at most a few rounds)
+                    const float step = __uint_as_float(e << 23);
+                    bool ok = true;
+                    uint32_t lo_pack = 0, hi_pack = 0;
+                    for (int k = 0; k < nc; ++k) {
+                        float lo = floorf((cmn[k][ax] - org[ax]) / step);
+                        lo = fminf(fmaxf(lo, 0.0f), 255.0f);
+                        while (lo > 0.0f && __builtin_fmaf(lo, step, org[ax]) > cmn[k][ax]) lo -= 1.0f;
+                        float hi = ceilf((cmx[k][ax] - org[ax]) / step);
+                        hi = fminf(fmaxf(hi, 0.0f), 255.0f);
+                        while (hi < 255.0f && __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) hi += 1.0f;
+                        if (__builtin_fmaf(lo, step, org[ax]) > cmn[k][ax] || __builtin_fmaf(hi, step, org[ax]) < cmx[k][ax]) ok = false;
+                        lo_pack |= (uint32_t)lo << (8 * k);
+                        hi_pack |= (uint32_t)hi << (8 * k);
+                    }
+                    if (ok || e >= 254u) {
+                        qlo[ax] = lo_pack;
+                        qhi[ax] = hi_pack;
+                        eb[ax] = e;
+                        break;
+                    }
+                    ++e;
+                }
+            }
+            int ref[4] = {0, 0, 0, 0};
+            for (int k = 0; k < nc; ++k) {
+                ref[k] = child_ref(ch[k], n, bn, &my_leaves, leaf_max);
+                if (ref[k] >= 0) {                 // roots a node of the next level
+                    qout[pos] = ref[k];
+                    ref[k] = (int)(next_base + pos);
+                    ++pos;
+                }
+            }
+            BvhNode nd;
+            nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
+                              eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (spheres ? 0x80000000u : 0u));
+            nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+            nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
+            nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], rcode[0] | (rcode[1] << 16), rcode[2] | (rcode[3] << 16));
+            nodes[node_base + slot] = nd;
         }
-        BvhNode nd;
-        nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
-                          eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (spheres ? 0x80000000u : 0u));
-        nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-        nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
-        nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], rcode[0] | (rcode[1] << 16), rcode[2] | (rcode[3] << 16));
-        nodes[i] = nd;
-        ++my_nodes;
+        __syncthreads();   // s_base and lds4 are reused by the next pass
     }
-    if (my_nodes) atomicAdd(&s_nodes, my_nodes);     // LDS atomics
-    if (my_leaves) atomicAdd(&s_leaves, my_leaves);
+    if (my_leaves) atomicAdd(&s_leaves, my_leaves);     // LDS atomic
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_nodes) atomicAdd(&counts[0], s_nodes);
-        if (s_leaves) atomicAdd(&counts[1], s_leaves);
-    }
+    if (threadIdx.x == 0 && s_leaves) atomicAdd(&lvl[level].leaves, s_leaves);
 }
 
 // Traversal records, in `order` (sorted ids) or in id order when order == nullptr.
@@ -696,7 +776,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     // build); it stays with the context for the next build unless it is large. What does not fit falls back to hipMalloc.
     TmpArena tmp{ctx};
     {
-        const size_t want = (size_t)n * 224 + (8u << 20);
+        const size_t want = (size_t)n * 272 + (8u << 20);
         if (ctx->build_arena_size < want) {
             if (ctx->build_arena) (void)hipFree(ctx->build_arena);
             ctx->build_arena = nullptr;
@@ -742,27 +822,9 @@ int rtx_bvh_build(rtx_context* ctx) {
     for (int k = 0; k < 3; ++k) { init.cmin[k] = init.bmin[k] = 0xFFFFFFFFu; init.cmax[k] = init.bmax[k] = 0u; }
     TRY_HIP(hipMemcpyAsync(sb, &init, sizeof(init), hipMemcpyHostToDevice, st));
     if (n > 0) hipLaunchKernelGGL(k_bounds, dim3(grid_for(n, 1024)), dim3(kThreads), 0, st, s, bmin, bmax, sb);
+    // The bounds stay on the device for the Morton keys; the host reads them (safe region of the padded tests, needed
+    // in both modes) at the end of the build.
     SceneBounds hb;
-    TRY_HIP(hipMemcpyAsync(&hb, sb, sizeof(hb), hipMemcpyDeviceToHost, st));
-    TRY_HIP(hipStreamSynchronize(st));
-    float cmin[3], cmax[3], smin[3], smax[3];
-    for (int k = 0; k < 3; ++k) {
-        cmin[k] = dec_f32(hb.cmin[k]); cmax[k] = dec_f32(hb.cmax[k]);
-        smin[k] = dec_f32(hb.bmin[k]); smax[k] = dec_f32(hb.bmax[k]);
-        if (n == 0) cmin[k] = cmax[k] = smin[k] = smax[k] = 0.0f;
-        ctx->scene_min[k] = smin[k];
-        ctx->scene_max[k] = smax[k];
-    }
-    // Safe region: a cube around the scene that contains the camera with margin.
-    float radius = 0.0f, dcam = 0.0f;
-    for (int k = 0; k < 3; ++k) {
-        s.safe_c[k] = 0.5f * smin[k] + 0.5f * smax[k];
-        radius = std::max(radius, 0.5f * (smax[k] - smin[k]));
-        dcam = std::max(dcam, std::fabs(ctx->camera.pos[k] - s.safe_c[k]));
-    }
-    if (!std::isfinite(radius)) radius = 0.0f;
-    if (!std::isfinite(dcam)) dcam = 0.0f;
-    s.safe_r = std::max(std::max(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f);
     s.pad_rel = 1.0f / 131072.0f;   // 2^-17, about 128 ulp of the coordinate magnitude
     PadParams pp;
     pp.rel = s.pad_rel;
@@ -781,24 +843,10 @@ int rtx_bvh_build(rtx_context* ctx) {
         int bits = 4;
         while (bits < 21 && (1ull << (3 * bits)) < (uint64_t)n * 4096ull) ++bits;
         bs.key_bits = 3 * bits;
-        MortonParams mp;
-        mp.qmax = (float)((1u << bits) - 1u);
-        // One cell size for all three axes (the largest centroid extent spans the grid), so
-        // cells are cubes: a thin scene such as a height field is not stretched along its
-        // thin axis, which would interleave splits that separate nothing a ray cares about.
-        float max_ext = 0.0f;
-        for (int k = 0; k < 3; ++k) {
-            const float ext = cmax[k] - cmin[k];
-            if (std::isfinite(ext) && ext > max_ext) max_ext = ext;
-        }
-        for (int k = 0; k < 3; ++k) {
-            mp.cmin[k] = cmin[k];
-            mp.scale[k] = (max_ext > 0.0f) ? (float)(1u << bits) / max_ext : 0.0f;
-        }
         uint64_t* keys[2];
         uint32_t* vals[2];
         for (int k = 0; k < 2; ++k) { TRY(tmp.get(&keys[k], n)); TRY(tmp.get(&vals[k], n)); }
-        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, mp, keys[0], vals[0]);
+        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, sb, bits, keys[0], vals[0]);
 
         const uint32_t nb = (n + kSortTile - 1) / kSortTile;
         const uint32_t m = 256u * nb;
@@ -819,75 +867,97 @@ int rtx_bvh_build(rtx_context* ctx) {
         const uint64_t* skeys = keys[cur];
         const uint32_t* sids = vals[cur];
 
+        constexpr uint32_t kMaxLevels = 256;   // the binary tree is at most 255 high (k_refit saturates there)
         int* queue[2];
-        uint32_t *qcount, *counts;
+        LevelInfo* lvl;
+        uint32_t* root_height;
         BuildNode* bn;
+        float4* box;
+        BvhNode* nodes_tmp;
         const size_t total = 2 * (size_t)n - 1;
         TRY(tmp.get(&bn, total));
+        TRY(tmp.get(&box, 2 * total));
         TRY(tmp.get(&queue[0], n));
         TRY(tmp.get(&queue[1], n));
-        TRY(tmp.get(&qcount, 2));
-        TRY(tmp.get(&counts, 4));   // nodes, leaves, refit levels, emission levels
-        TRY_HIP(hipMemsetAsync(qcount, 0, 8, st));
-        TRY_HIP(hipMemsetAsync(counts, 0, 16, st));
+        TRY(tmp.get(&lvl, kMaxLevels + 2));
+        TRY(tmp.get(&root_height, 1));
+        TRY_HIP(hipMemsetAsync(lvl, 0, (kMaxLevels + 2) * sizeof(LevelInfo), st));
+        TRY_HIP(hipMemsetAsync(root_height, 0, 4, st));
         hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, bn);
-        hipLaunchKernelGGL(k_leaf_init, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax, bn, queue[0],
-                           &qcount[0], pp);
-        // Refit: one launch per level until the queue drains (the root pushes nothing). The host looks at the
-        // queue only every kLevelBatch launches; a launch that finds its queue empty does nothing.
-        constexpr int kLevelBatch = 8;
-        const uint32_t level_grid = (uint32_t)std::min<uint64_t>(grid_for(n), 2048);
-        int q = 0;
-        uint32_t levels = 0;
-        for (int round = 0;; ++round) {
-            for (int b = 0; b < kLevelBatch; ++b) {
-                TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
-                hipLaunchKernelGGL(k_refit_pass, dim3(level_grid), dim3(kThreads), 0, st, queue[q], &qcount[q], bn, queue[q ^ 1],
-                                   &qcount[q ^ 1], leaf_max, &counts[2]);
-                q ^= 1;
-            }
-            uint32_t cnt = 0;
-            TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
-            TRY_HIP(hipStreamSynchronize(st));
-            if (cnt == 0) break;
-            if (round > 512) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH refit did not terminate"); }
+        hipLaunchKernelGGL(k_refit, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax, bn, box, pp, leaf_max,
+                           root_height);
+        uint32_t* mismatches = nullptr;
+        if (ctx->opt_verify_build) {
+            TRY(tmp.get(&mismatches, 1));
+            TRY_HIP(hipMemsetAsync(mismatches, 0, 4, st));
+            hipLaunchKernelGGL(k_verify_refit, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, bn, box, leaf_max, mismatches);
         }
-        BvhNode* nodes = nullptr;
-        TRY(dev_alloc(ctx, store->ptrs, &nodes, n - 1));
-        TRY_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * sizeof(BvhNode), st));
-        // Emission: one launch per level of the 4-wide tree, from the root down (the refit queues are free now).
+        // The height bounds the number of emission launches; this is the build's only wait before its end.
+        uint32_t height = 0;
+        uint32_t bad_boxes = 0;
+        if (mismatches) TRY_HIP(hipMemcpyAsync(&bad_boxes, mismatches, 4, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipMemcpyAsync(&height, root_height, 4, hipMemcpyDeviceToHost, st));
+        TRY_HIP(hipStreamSynchronize(st));
+        if (bad_boxes) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "verify_build: " + std::to_string(bad_boxes) + " inner nodes whose box is not the union of their children's"); }
+        if (height == 0 || height >= 255) { cleanup(); return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows"); }
+        // Emission: one launch per level of the 4-wide tree, from the root down, into a temporary array with one slot per
+        // binary inner node (an upper bound); the nodes that exist are then copied to an allocation of their exact size.
+        TRY(tmp.get(&nodes_tmp, n - 1));
         {
             const int root = 0;
-            const uint32_t one = 1;
-            q = 0;
+            const LevelInfo first{1u, 0u};
             TRY_HIP(hipMemcpyAsync(queue[0], &root, 4, hipMemcpyHostToDevice, st));
-            TRY_HIP(hipMemcpyAsync(&qcount[0], &one, 4, hipMemcpyHostToDevice, st));
-            for (int round = 0;; ++round) {
-                for (int b = 0; b < kLevelBatch; ++b) {
-                    TRY_HIP(hipMemsetAsync(&qcount[q ^ 1], 0, 4, st));
-                    hipLaunchKernelGGL(k_emit4, dim3(level_grid), dim3(kThreads), 0, st, (int)n, queue[q], &qcount[q], queue[q ^ 1],
-                                       &qcount[q ^ 1], bn, nodes, counts, leaf_max, &counts[3]);
-                    q ^= 1;
-                }
-                uint32_t cnt = 0;
-                TRY_HIP(hipMemcpyAsync(&cnt, &qcount[q], 4, hipMemcpyDeviceToHost, st));
-                TRY_HIP(hipStreamSynchronize(st));
-                if (cnt == 0) break;
-                if (round > 512) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
+            TRY_HIP(hipMemcpyAsync(&lvl[0], &first, sizeof(first), hipMemcpyHostToDevice, st));
+            // a level of the 4-wide tree has at most min(4^level, n / 2) nodes: small grids for the top levels
+            uint64_t width = 1;
+            for (uint32_t level = 0; level < height; ++level) {
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_for(std::min<uint64_t>(width, n)), 2048);
+                hipLaunchKernelGGL(k_emit4, dim3(grid), dim3(kThreads), 0, st, (int)n, level, queue[level & 1], queue[(level & 1) ^ 1], lvl, bn, box,
+                                   nodes_tmp, leaf_max);
+                width = std::min<uint64_t>(width * 4, n);
             }
         }
         hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
-        uint32_t hcounts[4] = {0, 0, 0, 0};
-        TRY_HIP(hipMemcpyAsync(hcounts, counts, 16, hipMemcpyDeviceToHost, st));
+        std::vector<LevelInfo> hl(kMaxLevels + 2);
+        TRY_HIP(hipMemcpyAsync(hl.data(), lvl, hl.size() * sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
         TRY_HIP(hipStreamSynchronize(st));
-        bs.n_nodes = hcounts[0];
-        bs.n_leaves = hcounts[1];
-        levels = hcounts[2];
-        levels4 = hcounts[3];
-        bs.max_depth = levels;   // height of the binary tree; the 4-wide tree has about half of it
+        uint64_t n_nodes = 0, n_leaves = 0;
+        for (uint32_t level = 0; level < height && hl[level].count; ++level) {
+            n_nodes += hl[level].count;
+            n_leaves += hl[level].leaves;
+            levels4 = level + 1;
+        }
+        if (hl[height].count != 0 || n_nodes == 0 || n_nodes > (uint64_t)n - 1) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
+        BvhNode* nodes = nullptr;
+        TRY(dev_alloc(ctx, store->ptrs, &nodes, (size_t)n_nodes));
+        TRY_HIP(hipMemcpyAsync(nodes, nodes_tmp, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToDevice, st));
+        bs.n_nodes = (uint32_t)n_nodes;
+        bs.n_leaves = (uint32_t)n_leaves;
+        bs.max_depth = height;   // height of the binary tree; the 4-wide tree has about half of it
         s.recs = recs;
         s.nodes = nodes;
         s.uses_bvh = 1;
+    }
+    TRY_HIP(hipMemcpyAsync(&hb, sb, sizeof(hb), hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    {
+        float smin[3], smax[3];
+        for (int k = 0; k < 3; ++k) {
+            smin[k] = (n == 0) ? 0.0f : dec_f32(hb.bmin[k]);
+            smax[k] = (n == 0) ? 0.0f : dec_f32(hb.bmax[k]);
+            ctx->scene_min[k] = smin[k];
+            ctx->scene_max[k] = smax[k];
+        }
+        // Safe region: a cube around the scene that contains the camera with margin.
+        float radius = 0.0f, dcam = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            s.safe_c[k] = 0.5f * smin[k] + 0.5f * smax[k];
+            radius = std::max(radius, 0.5f * (smax[k] - smin[k]));
+            dcam = std::max(dcam, std::fabs(ctx->camera.pos[k] - s.safe_c[k]));
+        }
+        if (!std::isfinite(radius)) radius = 0.0f;
+        if (!std::isfinite(dcam)) dcam = 0.0f;
+        s.safe_r = std::max(std::max(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f);
     }
     {
         const uint32_t need = 3 * (levels4 + 1) + 4;   // levels4: height of the 4-wide tree (0 without a BVH)

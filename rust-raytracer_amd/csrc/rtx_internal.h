@@ -79,7 +79,7 @@ struct DevScene {
     const DevLight* lights;     // [n_lights]
     // traversal-side arrays
     const PrimRec* recs;        // [n_prims]
-    const BvhNode* nodes;       // [n_prims - 1] indexed by binary-tree node; only even-depth, non-collapsed entries are used
+    const BvhNode* nodes;       // [n_nodes] in level order (node 0 is the root), one slot per node
     // Rays whose origin lies outside the cube |o - safe_c|_inf <= safe_r take the
     // exhaustive loop: the sphere padding of the BVH is only proven inside it.
     float safe_c[3];
@@ -158,6 +158,7 @@ struct rtx_context {
     float hit_fraction = 1.0f;   // share of the last frame's closest-hit rays that hit something
     uint32_t trav_spill_need = 0;   // stack entries beyond the LDS part that a traversal of the built tree can need
     int64_t opt_stamps = 0;
+    int64_t opt_verify_build = 0;   // rtx_build re-checks every box of the refit (tests)
 
     // Frames in flight (rtx_render_*_async / rtx_render_wait): a frame whose kernels need no host
     // decision (one batch, one level) is only enqueued; its counters land in the slot's pinned

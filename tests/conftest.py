@@ -43,6 +43,7 @@ def gpu_ctx_factory(rtx):
 
     def make(flat, force_mode=0):
         ctx = rtx.Context(0)
+        ctx.set_option("verify_build", 1)      # every tree built by the tests has its refit re-checked box by box
         if force_mode:
             ctx.set_option("force_mode", force_mode)
         ctx.set_scene(flat)

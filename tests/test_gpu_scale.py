@@ -44,6 +44,7 @@ def scene(request, rtx):
     flat = synth.heightfield_scene(cfg["grid"], spec=cfg["spec"], glass_lattice=cfg["glass"], small_spheres=cfg["spheres"])
     assert (flat.n_tris, flat.n_spheres) == (cfg["n_tris"], cfg["n_spheres"])
     ctx = rtx.Context(0)
+    ctx.set_option("verify_build", 1)
     _beat("config %d: upload and build" % request.param)
     ctx.set_scene(flat)
     ctx.build()
