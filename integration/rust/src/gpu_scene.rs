@@ -1,0 +1,171 @@
+//! gpu_scene.rs -- the reference crate's `Scene` on the GPU.
+//!
+//! `GpuScene` owns an `rtx_context` holding the flattened scene and its tree. It implements
+//! `IntersectableScene` (src/scene/mod.rs:148-154), so `RayTracer::set_scene` (src/lib.rs:64-67) takes it like
+//! `Scene` or `BvhScene`; `render` is the whole-frame replacement for the pixel loop of `RayTracer::trace_rays`
+//! (src/lib.rs:257-277). Written against the crate's early-2015 types; never compiled (no Rust toolchain here).
+use std::ffi::{CStr, CString};
+use std::ptr;
+
+use bmp::{Image, Pixel};
+use ffi::*;
+use ray::Ray;
+use scene::intersection::Intersection;
+use scene::shapes::Primitive;
+use scene::{Camera, IntersectableScene, Light, Scene, SceneIntersection};
+
+pub struct GpuScene {
+    ctx: *mut rtx_context,
+    scene: Scene, // keeps camera, lights and primitives for get_camera / get_lights / the returned Intersection
+    pub build: rtx_build_stats,
+}
+
+fn check(ctx: *const rtx_context, status: i32, what: &str) {
+    if status != RTX_OK {
+        let msg = unsafe { CStr::from_ptr(rtx_last_error(ctx)) }.to_string_lossy().into_owned();
+        panic!("{}: {}", what, msg); // the reference's error convention (src/lib.rs:72,275)
+    }
+}
+
+impl GpuScene {
+    /// Flattening rules: primitive id = index in `scene.primitives` (the parser has already reversed every poly_set,
+    /// src/scene/parser/mod.rs:333-338); a poly's `materials` is its de-duplicated list (parser/mod.rs:266-291).
+    pub fn new(scene: Scene, device: i32, force_bvh: bool) -> GpuScene {
+        let mut tri_pos: Vec<f32> = Vec::new();
+        let mut tri_nrm: Vec<f32> = Vec::new();
+        let mut tri_mat: Vec<u32> = Vec::new();
+        let mut tri_flags: Vec<u8> = Vec::new();
+        let mut tri_index: Vec<u32> = Vec::new();
+        let mut sph: Vec<f32> = Vec::new();
+        let mut sph_mat: Vec<u32> = Vec::new();
+        let mut sph_index: Vec<u32> = Vec::new();
+        let mut materials: Vec<rtx_material> = Vec::new();
+        let mut push_material = |m: &::scene::material::Material| -> u32 {
+            materials.push(rtx_material {
+                diffuse: [m.diffuse.r_val(), m.diffuse.g_val(), m.diffuse.b_val()],
+                ambient: [m.ambient.r_val(), m.ambient.g_val(), m.ambient.b_val()],
+                specular: [m.specular.r_val(), m.specular.g_val(), m.specular.b_val()],
+                emissive: [m.emissive.r_val(), m.emissive.g_val(), m.emissive.b_val()],
+                shininess: m.shininess,
+                transparency: m.transparency,
+            });
+            (materials.len() - 1) as u32
+        };
+        for (id, prim) in scene.primitives.iter().enumerate() {
+            match *prim {
+                Primitive::Poly(ref p) => {
+                    for v in p.vertices.iter() {
+                        tri_pos.extend_from_slice(&[v.pos.x, v.pos.y, v.pos.z]);
+                        tri_nrm.extend_from_slice(&[v.normal.x, v.normal.y, v.normal.z]);
+                    }
+                    for k in 0..3 {
+                        tri_mat.push(if k < p.materials.len() { push_material(&p.materials[k]) } else { RTX_MATERIAL_NONE });
+                    }
+                    tri_flags.push((if p.vertex_normal { RTX_TRI_VERTEX_NORMAL } else { 0 })
+                        | (if p.vertex_material { RTX_TRI_VERTEX_MATERIAL } else { 0 }));
+                    tri_index.push(id as u32);
+                }
+                Primitive::Sphere(ref s) => {
+                    sph.extend_from_slice(&[s.origin.x, s.origin.y, s.origin.z, s.radius]);
+                    sph_mat.push(push_material(&s.materials[0]));
+                    sph_index.push(id as u32);
+                }
+            }
+        }
+        let lights: Vec<rtx_light> = scene.lights.iter().map(|l| match *l {
+            Light::Point(ref p) => rtx_light { type_: RTX_LIGHT_POINT, a: [p.position.x, p.position.y, p.position.z], b: [0.0; 3],
+                                               color: [p.intensity.r_val(), p.intensity.g_val(), p.intensity.b_val()] },
+            Light::Area(ref a) => rtx_light { type_: RTX_LIGHT_AREA, a: [a.min.x, a.min.y, a.min.z], b: [a.max.x, a.max.y, a.max.z],
+                                              color: [a.intensity.r_val(), a.intensity.g_val(), a.intensity.b_val()] },
+            Light::Directional(ref d) => rtx_light { type_: RTX_LIGHT_DIRECTIONAL, a: [d.direction.x, d.direction.y, d.direction.z],
+                                                     b: [0.0; 3], color: [d.intensity.r_val(), d.intensity.g_val(), d.intensity.b_val()] },
+        }).collect();
+        let cam = &scene.camera;
+        let desc = rtx_scene_desc {
+            n_tris: tri_index.len() as u32,
+            tri_pos: tri_pos.as_ptr(),
+            tri_normals: tri_nrm.as_ptr(),
+            tri_mat: tri_mat.as_ptr(),
+            tri_flags: tri_flags.as_ptr(),
+            tri_prim_index: tri_index.as_ptr(),
+            n_spheres: sph_index.len() as u32,
+            sph_center_radius: sph.as_ptr(),
+            sph_mat: sph_mat.as_ptr(),
+            sph_prim_index: sph_index.as_ptr(),
+            n_materials: materials.len() as u32,
+            materials: materials.as_ptr(),
+            n_lights: lights.len() as u32,
+            lights: lights.as_ptr(),
+            camera: rtx_camera {
+                pos: [cam.pos.x, cam.pos.y, cam.pos.z],
+                view_dir: [cam.view_dir.x, cam.view_dir.y, cam.view_dir.z],
+                ortho_up: [cam.ortho_up.x, cam.ortho_up.y, cam.ortho_up.z],
+                focal_dist: cam.focal_dist,
+                vertical_fov: cam.vertical_fov,
+            },
+        };
+        let mut ctx: *mut rtx_context = ptr::null_mut();
+        check(ptr::null(), unsafe { rtx_create(device, &mut ctx) }, "rtx_create");
+        if force_bvh {
+            let key = CString::new("force_mode").unwrap();
+            check(ctx, unsafe { rtx_set_option(ctx, key.as_ptr(), 2) }, "rtx_set_option");
+        }
+        check(ctx, unsafe { rtx_scene_set(ctx, &desc) }, "rtx_scene_set");
+        let mut build = rtx_build_stats::default();
+        check(ctx, unsafe { rtx_build(ctx, &mut build) }, "rtx_build");
+        GpuScene { ctx: ctx, scene: scene, build: build }
+    }
+
+    /// Batched `intersects`: (primitive index or -1, t) per ray.
+    pub fn intersect_batch(&self, rays: &[Ray]) -> Vec<(i32, f32)> {
+        let mut ori = Vec::with_capacity(rays.len() * 3);
+        let mut dir = Vec::with_capacity(rays.len() * 3);
+        for r in rays {
+            ori.extend_from_slice(&[r.ori.x, r.ori.y, r.ori.z]);
+            dir.extend_from_slice(&[r.dir.x, r.dir.y, r.dir.z]);
+        }
+        let mut prim = vec![-1i32; rays.len()];
+        let mut t = vec![0f32; rays.len()];
+        check(self.ctx, unsafe { rtx_intersect_batch(self.ctx, rays.len() as u64, ori.as_ptr(), dir.as_ptr(),
+                                                      prim.as_mut_ptr(), t.as_mut_ptr()) }, "rtx_intersect_batch");
+        prim.into_iter().zip(t.into_iter()).collect()
+    }
+
+    /// The whole frame: what the loop of `RayTracer::trace_rays` (src/lib.rs:262-271) produces, row 0 = top row.
+    pub fn render(&self, width: u32, height: u32, depth: usize, num_samples: usize) -> (Image, rtx_render_stats) {
+        let mut rgb = vec![0u8; (width as usize) * (height as usize) * 3];
+        let mut stats = rtx_render_stats::default();
+        check(self.ctx, unsafe { rtx_render(self.ctx, width, height, depth as u32, num_samples as u32, rgb.as_mut_ptr(), &mut stats) },
+              "rtx_render");
+        let mut img = Image::new(width, height);
+        for (x, y) in img.coordinates() {
+            let i = ((y * width + x) * 3) as usize;
+            img.set_pixel(x, y, Pixel { r: rgb[i], g: rgb[i + 1], b: rgb[i + 2] }); // where src/lib.rs:268 sets it
+        }
+        (img, stats)
+    }
+}
+
+impl Drop for GpuScene {
+    fn drop(&mut self) {
+        unsafe { rtx_destroy(self.ctx) }
+    }
+}
+
+impl<'a> IntersectableScene<'a> for GpuScene {
+    fn get_camera(&self) -> &Camera {
+        &self.scene.camera
+    }
+    fn get_lights(&self) -> &[Light] {
+        &self.scene.lights
+    }
+    /// One-ray form of the batched call (a device round trip per ray: for parity checks, not for rendering).
+    fn intersects(&'a self, ray: &Ray) -> SceneIntersection<'a> {
+        let (prim, t) = self.intersect_batch(&[ray.clone()])[0];
+        if prim < 0 {
+            SceneIntersection::Missed
+        } else {
+            SceneIntersection::Intersected(Intersection::new(t, ray.clone(), &self.scene.primitives[prim as usize]))
+        }
+    }
+}

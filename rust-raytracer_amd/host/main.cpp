@@ -2,7 +2,10 @@
 //   -h  -b  -s SIZE  -a SAMPLES  -d DEPTH  -i SCENE  -o OUT
 // Defaults as in main.rs:63-67: size 100, samples 10, depth 10, scene test01,
 // output img.bmp. Unparsable numbers fall back to the default (main.rs:20-25).
-// `-b` is accepted for compatibility: the GPU path always uses its own BVH.
+// `-b`: the reference switches from the exhaustive Scene to its BvhScene (main.rs:70-74). Here scenes above 16
+// primitives use the GPU tree either way; `-b` builds it for smaller scenes too (they are otherwise swept
+// exhaustively on the device). Unlike the reference's own `-b`, whose tie rule differs (bvh.rs:134), the image
+// does not depend on the flag: both paths return the exhaustive loop's hits.
 // Additions: -W/-H for non-square frames, -g DEVICE.
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +22,7 @@ static long get_opt(const char* s, long dflt) {
 }
 
 int main(int argc, char** argv) {
+    bool force_bvh = false;
     const char *s = nullptr, *a = nullptr, *d = nullptr, *i = nullptr, *o = nullptr, *W = nullptr, *H = nullptr, *g = nullptr;
     for (int k = 1; k < argc; ++k) {
         const std::string f = argv[k];
@@ -29,7 +33,7 @@ int main(int argc, char** argv) {
         if (f == "-h" || f == "--help") {
             std::printf("Usage: %s [options]\n\nOptions:\n"
                         "    -h --help           Print this help menu\n"
-                        "    -b --bvh            Optimize scene intersection with BVH-tree\n"
+                        "    -b --bvh            Optimize scene intersection with BVH-tree (always on above 16 primitives; the image is the same)\n"
                         "    -s --size -s 500    The width and height of the image to be generated\n"
                         "    -a --arealight-samples -a 1000\n                        The number of times to sample the area lights\n"
                         "    -d --depth -d 10    The depth of the recursion in the main loop\n"
@@ -37,6 +41,7 @@ int main(int argc, char** argv) {
                         "    -o --out -o image.bmp\n                        The name of the image to be generated\n", argv[0]);
             return 0;
         } else if (f == "-b" || f == "--bvh") {
+            force_bvh = true;
         } else if (f == "-s" || f == "--size") val(&s);
         else if (f == "-a" || f == "--arealight-samples") val(&a);
         else if (f == "-d" || f == "--depth") val(&d);
@@ -56,7 +61,7 @@ int main(int argc, char** argv) {
         rstracer::SceneParser parser(scene_path);
         rstracer::Scene scene = parser.parse_scene();
         rstracer::RayTracer tracer = rstracer::RayTracer::init((uint32_t)width, (uint32_t)height, (size_t)depth, (size_t)samples);
-        tracer.set_scene(std::make_unique<rstracer::GpuScene>(scene, (int)get_opt(g, 0)));
+        tracer.set_scene(std::make_unique<rstracer::GpuScene>(scene, (int)get_opt(g, 0), force_bvh));
         tracer.trace_rays().save(out);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "thread 'main' panicked at '%s'\n", e.what());   // the reference aborts with a panic message

@@ -385,9 +385,10 @@ rtx_scene_desc FlatScene::desc() const {
 static void check(rtx_context* ctx, int rc, const char* what) {
     if (rc != RTX_OK) throw Error(std::string(what) + ": " + rtx_last_error(ctx));
 }
-GpuScene::GpuScene(const Scene& scene, int device) : camera_(scene.camera), lights_(scene.lights) {
+GpuScene::GpuScene(const Scene& scene, int device, bool force_bvh) : camera_(scene.camera), lights_(scene.lights) {
     int rc = rtx_create(device, &ctx_);
     if (rc != RTX_OK) throw Error(std::string("rtx_create: ") + rtx_last_error(nullptr));
+    if (force_bvh) (void)rtx_set_option(ctx_, "force_mode", 2);
     const FlatScene flat = flatten(scene);
     const rtx_scene_desc d = flat.desc();
     rc = rtx_scene_set(ctx_, &d);

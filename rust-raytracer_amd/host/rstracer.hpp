@@ -136,7 +136,9 @@ FlatScene flatten(const Scene& scene);
 // owns an rtx_context with the scene uploaded and built.
 class GpuScene {
 public:
-    explicit GpuScene(const Scene& scene, int device = 0);
+    // force_bvh: what the reference's `-b` flag selects (BvhScene instead of Scene, src/main.rs:70-74). Here the tree is
+    // then built even for the few-primitive scenes the library would otherwise sweep exhaustively; results are the same.
+    explicit GpuScene(const Scene& scene, int device = 0, bool force_bvh = false);
     ~GpuScene();
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
