@@ -151,6 +151,10 @@ def main():
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal: "
                          "collectives through host memory, ranks may share a GPU)")
+    ap.add_argument("--collectives", type=str, default="torch", choices=("torch", "abi"),
+                    help="N > 1: who runs the exchange steps. torch: torch.distributed broadcast / all-gather (RCCL underneath); "
+                         "abi: the library's own entry points (rtx_comm_init, rtx_scene_broadcast, rtx_gather_frame: RCCL "
+                         "broadcast and gather-to-root), as a Rust or C++ host would call them")
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5),
                     help="BASELINE configuration: 3 = 1M triangles at 1080p (default, the single-GPU bench workload), 4 = 16M triangles + "
                          "64 glass spheres at 4K depth 5, 5 = 62.72M triangles + 1.28M spheres at 8K depth 5")
@@ -211,7 +215,10 @@ def main():
     t_b0 = time.time()
     bcast_collective_ms = None
     scene_meta = scene_tensors = None
-    if multi:
+    abi = multi and not gloo and args.collectives == "abi"
+    if abi:
+        pass          # the library replicates the scene itself, below, once the context exists
+    elif multi:
         timing = {}
         if gloo:      # rehearsal through host memory
             flat = rdist.broadcast_scene(flat, 0, cdev, timing=timing)
@@ -232,7 +239,16 @@ def main():
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
         ctx.set_option("tune%d" % i, int(v))
     t_s0 = time.time()
-    if scene_tensors is not None:
+    if abi:
+        ids = [rtx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)          # the 128-byte id travels over the host channel we already have
+        ctx.comm_init(rank, world, ids[0])
+        torch.cuda.synchronize()
+        t_c0 = time.perf_counter()
+        ctx.scene_broadcast(flat if rank == 0 else None, 0)
+        bcast_collective_ms = (time.perf_counter() - t_c0) * 1e3     # upload on the root + broadcasts + device copies
+        bcast_ms = bcast_collective_ms
+    elif scene_tensors is not None:
         ctx.set_scene_device(scene_meta, scene_tensors)
         scene_tensors = None      # copied device-to-device by the library
         torch.cuda.empty_cache()
@@ -281,7 +297,7 @@ def main():
     # GPU-side ordering between the library's streams, torch's current stream and RCCL's stream (no host waits):
     # slab k is read by all-gather k and rewritten by render k + ring; gathered k is written by all-gather k,
     # read by assembly k and rewritten by all-gather k + ring.
-    lib_streams = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs] if (multi and not gloo) else None
+    lib_streams = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs] if (multi and not gloo and not abi) else None
     TIMED_EVERY = 16
     timing_state = [1] * len(ctxs)
     gather_done = [None] * ring      # recorded on torch's stream once all-gather k has been waited for there
@@ -311,6 +327,9 @@ def main():
         idx = state["collected"] % ring
         state["collected"] += 1
         if not multi:
+            return
+        if abi:      # gather-to-root and assembly inside the library; rank 0 ends up with the image
+            ctx.gather_frame(w, h, slabs[idx].data_ptr(), image.data_ptr(), 0)
             return
         if gloo:
             dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
@@ -385,7 +404,16 @@ def main():
         torch.cuda.synchronize()
         sharded_equal = bool(torch.equal(whole, image))
     gather_isolated_ms = None
-    if multi and not gloo:     # the exchange step alone: 10 all-gathers of the slabs, nothing else on the GPU
+    if abi:                    # the exchange step alone: 10 gathers to the root, nothing else on the GPU
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_g0 = time.perf_counter()
+        for _ in range(10):
+            ctx.gather_frame(w, h, slabs[0].data_ptr(), image.data_ptr(), 0)
+        gather_isolated_ms = (time.perf_counter() - t_g0) * 1e3 / 10
+        ctx.render_tiles(w, h, args.depth, 10, rank, world, slabs[0].data_ptr())      # the image the check below looks at
+        ctx.gather_frame(w, h, slabs[0].data_ptr(), image.data_ptr(), 0)
+    elif multi and not gloo:   # the exchange step alone: 10 all-gathers of the slabs, nothing else on the GPU
         torch.cuda.synchronize()
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -487,7 +515,7 @@ def main():
                                    "LBVH traversal, scene and BVH resident in HBM; one step = %d frames"
                                    % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth, "frames_per_step": fps,
-                       "parallelism": ("tile-sharded x%d (%s)" % (world, args.backend)) if multi else "single GPU",
+                       "parallelism": ("tile-sharded x%d (%s, %s collectives)" % (world, args.backend, args.collectives)) if multi else "single GPU",
                        "ranks": world, "frames_in_flight_per_gpu": len(ctxs) + 1},
             "ms_per_frame": elapsed / frames * 1e3,
             "rays_per_frame": total_traced / frames,

@@ -273,6 +273,28 @@ int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32
 int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
                              const uint8_t* d_slabs, uint8_t* d_rgb);
 
+/* ---- exchange steps of a tile-sharded frame (no counterpart in the reference, which has no second device) -----
+ * One process per GPU, one context per process. The scene is replicated once from a root rank into every rank's
+ * HBM; every frame, each rank renders its interleaved tiles (rtx_render_tiles) and the slabs are gathered to the
+ * root, which assembles the image. Both steps run over RCCL (xGMI inside a node) on the context's stream; librccl
+ * is loaded when rtx_comm_unique_id / rtx_comm_init is first called (RTX_ERR_UNSUPPORTED if it cannot be).
+ *   rtx_comm_unique_id  fills 128 bytes on ONE rank; the caller hands them to the other ranks by any host channel
+ *                       (a file, a socket, MPI, torch.distributed)
+ *   rtx_comm_init       collective: every rank calls it with the same id, its rank and the number of ranks
+ *   rtx_scene_broadcast collective: the root passes its flattened scene (host arrays, as for rtx_scene_set), the
+ *                       other ranks pass NULL; afterwards every rank holds the scene as if it had called
+ *                       rtx_scene_set, and calls rtx_build itself (building is cheaper than moving the tree)
+ *   rtx_gather_frame    collective: d_rgb_tiles = this rank's slab from rtx_render_tiles (device memory); on the root
+ *                       d_rgb receives the row-major [h][w][3] image (device memory; ignored elsewhere). Returns
+ *                       when this rank's part is complete. A gather: each slab crosses one link once. */
+#define RTX_COMM_ID_BYTES 128
+int rtx_comm_unique_id(uint8_t* id128);
+int rtx_comm_init(rtx_context* ctx, uint32_t rank, uint32_t world, const uint8_t* id128);
+int rtx_comm_destroy(rtx_context* ctx);
+int rtx_scene_broadcast(rtx_context* ctx, const rtx_scene_desc* scene, uint32_t root);
+int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles, uint8_t* d_rgb,
+                     uint32_t root);
+
 /* Diagnostics (no counterpart in the reference): with the "stamps" option set, every
  * wavefront of the last closest-hit launch (kind 0) or shadow launch (kind 1) has
  * recorded 4 x u64: start and end on the 100 MHz constant clock, work units of 64

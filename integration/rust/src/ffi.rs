@@ -21,6 +21,7 @@ pub const RTX_LIGHT_DIRECTIONAL: u32 = 2;
 pub const RTX_TRI_VERTEX_NORMAL: u8 = 1;
 pub const RTX_TRI_VERTEX_MATERIAL: u8 = 2;
 pub const RTX_NOALLOC_MAX_RAYS: u64 = 1 << 26;
+pub const RTX_COMM_ID_BYTES: usize = 128;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -142,6 +143,12 @@ extern "C" {
                               d_rgb: *mut u8) -> c_int;
     pub fn rtx_assemble_tiles_async(ctx: *mut rtx_context, width: u32, height: u32, world: u32, d_slabs: *const u8,
                                     d_rgb: *mut u8) -> c_int;
+    pub fn rtx_comm_unique_id(id128: *mut u8) -> c_int;
+    pub fn rtx_comm_init(ctx: *mut rtx_context, rank: u32, world: u32, id128: *const u8) -> c_int;
+    pub fn rtx_comm_destroy(ctx: *mut rtx_context) -> c_int;
+    pub fn rtx_scene_broadcast(ctx: *mut rtx_context, scene: *const rtx_scene_desc, root: u32) -> c_int;
+    pub fn rtx_gather_frame(ctx: *mut rtx_context, width: u32, height: u32, d_rgb_tiles: *const u8, d_rgb: *mut u8,
+                            root: u32) -> c_int;
     pub fn rtx_debug_stamps(ctx: *mut rtx_context, kind: c_int, out: *mut u64, capacity: u64) -> u64;
     pub fn rtx_stream(ctx: *mut rtx_context) -> *mut c_void;
 }

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
     "rtx_intersect_batch_device_noalloc", "rtx_scene_set_device", "rtx_clone",
+    "rtx_comm_unique_id", "rtx_comm_init", "rtx_comm_destroy", "rtx_scene_broadcast", "rtx_gather_frame",
 ]
 
 
@@ -154,6 +155,11 @@ def lib():
         L.rtx_render_device_async.argtypes = [vp, u32, u32, u32, u32, vp]
         L.rtx_render_tiles_async.argtypes = [vp, u32, u32, u32, u32, u32, u32, vp]
         L.rtx_render_wait.argtypes = [vp, C.POINTER(RenderStats)]
+        L.rtx_comm_unique_id.argtypes = [vp]
+        L.rtx_comm_init.argtypes = [vp, u32, u32, vp]
+        L.rtx_comm_destroy.argtypes = [vp]
+        L.rtx_scene_broadcast.argtypes = [vp, vp, u32]
+        L.rtx_gather_frame.argtypes = [vp, u32, u32, vp, vp, u32]
         L.rtx_debug_stamps.argtypes = [vp, C.c_int, vp, u64]
         L.rtx_debug_stamps.restype = u64
         _lib = L
@@ -354,6 +360,27 @@ class Context:
         d.camera = meta["camera"]
         self._check(self._L.rtx_scene_set_device(self._h, C.cast(C.byref(d), C.c_void_p)))
 
+    # -- exchange steps of a tile-sharded frame over RCCL (one process per GPU) --
+    def comm_init(self, rank, world, comm_id):
+        """Collective: every rank passes the 128 bytes that comm_unique_id() returned on one of them."""
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        self._check(self._L.rtx_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    def comm_destroy(self):
+        self._check(self._L.rtx_comm_destroy(self._h))
+
+    def scene_broadcast(self, flat, root=0):
+        """Collective: `flat` on the root rank, None elsewhere; afterwards every rank holds the scene (then build())."""
+        if flat is None:
+            self._check(self._L.rtx_scene_broadcast(self._h, None, int(root)))
+        else:
+            d, keep = flat.desc()
+            self._check(self._L.rtx_scene_broadcast(self._h, C.cast(C.byref(d), C.c_void_p), int(root)))
+
+    def gather_frame(self, width, height, d_rgb_tiles, d_rgb, root=0):
+        """Collective: this rank's slab (device pointer) to the root, which assembles the image into d_rgb (device pointer)."""
+        self._check(self._L.rtx_gather_frame(self._h, width, height, d_rgb_tiles, d_rgb, int(root)))
+
     def build(self):
         st = BuildStats()
         self._check(self._L.rtx_build(self._h, C.byref(st)))
@@ -435,6 +462,15 @@ class Context:
     def assemble_tiles_async(self, width, height, world, d_slabs, d_rgb):
         """Enqueues the assembly on the context's stream (see stream()) and returns."""
         self._check(self._L.rtx_assemble_tiles_async(self._h, width, height, world, d_slabs, d_rgb))
+
+
+def comm_unique_id():
+    """128 bytes naming a new communicator (rtx_comm_unique_id); call on one rank and hand them to the others."""
+    buf = C.create_string_buffer(128)
+    rc = lib().rtx_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != RTX_OK:
+        raise RtxError(rc, lib().rtx_last_error(None).decode())
+    return buf.raw
 
 
 def tiles_per_rank(width, height, world):

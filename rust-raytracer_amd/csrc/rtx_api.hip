@@ -120,6 +120,7 @@ void rtx_destroy(rtx_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)rtx_comm_destroy(ctx);
     rtx_clear_graphs(ctx);
     ctx->scene_store.reset();
     ctx->build_store.reset();

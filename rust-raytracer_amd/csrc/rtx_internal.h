@@ -135,6 +135,11 @@ struct rtx_context {
     // one buffer that only grows, so calls of a steady size allocate nothing after the first
     void* io_buf = nullptr;
     size_t io_size = 0;
+    // tile-sharded frames over RCCL (rtx_comm.hip): communicator of this rank, gather buffer of the root
+    void* comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 0;
+    void* gather_buf = nullptr;
+    size_t gather_size = 0;
     // render workspace (grown on demand)
     std::vector<void*> work_allocs;
     uint64_t work_batch = 0;      // pixels per batch the workspace was sized for
