@@ -837,6 +837,7 @@ int rtx_bvh_build(rtx_context* ctx) {
         if (n > 0) hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, (const uint32_t*)nullptr, recs);
         s.recs = recs;
         s.nodes = nullptr;
+        s.n_nodes = 0;
         s.uses_bvh = 0;
     } else {
         // Morton keys: enough bits per axis to separate ~n cells, at most 21.
@@ -936,6 +937,7 @@ int rtx_bvh_build(rtx_context* ctx) {
         bs.max_depth = height;   // height of the binary tree; the 4-wide tree has about half of it
         s.recs = recs;
         s.nodes = nodes;
+        s.n_nodes = (uint32_t)n_nodes;
         s.uses_bvh = 1;
     }
     TRY_HIP(hipMemcpyAsync(&hb, sb, sizeof(hb), hipMemcpyDeviceToHost, st));

@@ -49,7 +49,7 @@ constexpr unsigned long long kCoopMiss = ((unsigned long long)0x7f800000u << 32)
 //                        (dist_light < 0: any hit occludes), else 0.
 // SPH: the scene holds spheres (false: triangle-only code, see record_hit).
 template <bool ANY, bool SPH = true>
-RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_light, TravStack& st, CoopLds& L, int threshold,
+RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, V3 d, float dist_light, TravStack& st, CoopLds& L, int threshold,
                       float& out_t, int& out_id) {
     const int lane = threadIdx.x & 63;
     float best_t = __builtin_inff();
@@ -98,7 +98,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
         const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
         if (cur != kRefDone) {
-            const Fetched f = fetch_ref(s, cur);
+            const Fetched f = fetch_ref(s, tc, cur);
 #ifdef RTX_COUNT_STEPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long c1 = __builtin_readcyclecounter();
@@ -204,7 +204,7 @@ RTX_D void coop_trace(const DevScene& s, bool active, V3 o, V3 d, float dist_lig
                 cur = kRefDone;
                 sp = bot;
             } else {
-                const Fetched f = fetch_ref(s, cur);
+                const Fetched f = fetch_ref(s, tc, cur);
 #ifdef RTX_COUNT_STEPS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned long long d2 = __builtin_readcyclecounter();

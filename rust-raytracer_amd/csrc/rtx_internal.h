@@ -65,6 +65,7 @@ struct DevLight {  // 48 B
 struct DevScene {
     uint32_t n_prims, n_tris, n_spheres, n_lights, n_materials;
     uint32_t uses_bvh;
+    uint32_t n_nodes;           // traversal nodes (0 without a tree)
     uint32_t has_transparent;   // some material has transparency != 0
     uint32_t n_area_lights;     // lights of type RTX_LIGHT_AREA (each takes num_samples shadow rays per hit)
     // shading-side arrays, indexed through prim_ref by reference primitive id

@@ -373,8 +373,11 @@ template <bool SPH>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
+    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
     TravStack st;
     st.set(lds, s);
+    TopCache tc;
+    tc.load(top_lds, s);
     if (ctl->overflow) return;   // the batch is being abandoned
     const uint32_t n = ctl->n_rays[qi];
     WaveStamp ws;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(De
         }
         int id = -1;
         float t = 0.0f;
-        coop_trace<false, SPH>(s, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
+        coop_trace<false, SPH>(s, tc, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
         const uint64_t hits = __ballot(i < n && id >= 0);
@@ -716,8 +719,11 @@ template <bool ANY, bool AREA, bool SPH>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
+    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
     TravStack st;
     st.set(lds, s);
+    TopCache tc;
+    tc.load(top_lds, s);
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     ShadowTask<AREA> task;
@@ -734,27 +740,44 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScen
     UnitQueue uq;
     uq.init(&ctl->unit_head[1][0][0], total, uo);
     uq.announce();
+#ifdef RTX_COUNT_STEPS
+    unsigned long long dq0 = __builtin_readcyclecounter();
+#endif
     for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
         const unsigned long long unit_start = wall_clock64();
+#ifdef RTX_COUNT_STEPS
+        const unsigned long long su0 = __builtin_readcyclecounter();
+        st.t_deq += su0 - dq0;
+#endif
         ++ws.units;
         const uint64_t k = (uint64_t)unit * 64 + (threadIdx.x & 63);
         V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
         float dl = -1.0f, t;
         int id;
         bool live = k < total && task.start((uint32_t)k, o, d, dl);
+#ifdef RTX_COUNT_STEPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        st.t_setup += __builtin_readcyclecounter() - su0;
+#endif
         if (ANY) {
-            coop_trace<true, SPH>(s, live, o, d, dl, st, coop, s.tune[0], t, id);
+            coop_trace<true, SPH>(s, tc, live, o, d, dl, st, coop, s.tune[0], t, id);
             if (live) task.finish_any(id != 0);
         } else {
             while (__ballot(live)) {   // all lanes stay in the loop: the traversal is cooperative
-                coop_trace<false, SPH>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+                coop_trace<false, SPH>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
                 if (live) live = task.finish_closest(id, t, o, d);
             }
         }
         uq.record(unit, unit_start);
+#ifdef RTX_COUNT_STEPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        dq0 = __builtin_readcyclecounter();
+#endif
     }
 #ifdef RTX_COUNT_STEPS
-    ws.prof = ((st.t_mem >> 8) & 0x1fffff) | (((st.t_alu >> 8) & 0x1fffff) << 21) | (((st.t_don >> 8) & 0x1fffff) << 42);
+    // five shares of the wavefront's life in units of 256 shader cycles, 12 bits each: fetch wait, compute, giving work, taking units, ray set-up
+    ws.prof = ((st.t_mem >> 8) & 0xfff) | (((st.t_alu >> 8) & 0xfff) << 12) | (((st.t_don >> 8) & 0xfff) << 24) |
+              (((st.t_deq >> 8) & 0xfff) << 36) | (((st.t_setup >> 8) & 0xfff) << 48);
 #endif
     ws.end();
     unsigned long long rays = task.rays;

@@ -26,8 +26,11 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n,
                                                          float* __restrict__ tout, int exhaustive) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
+    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
     TravStack st;
     st.set(lds, s);
+    TopCache tc;
+    tc.load(top_lds, s);
     // block-uniform trip count: the BVH query is cooperative inside a wavefront
     for (uint64_t base = (uint64_t)blockIdx.x * RTX_BLOCK; base < n; base += (uint64_t)gridDim.x * RTX_BLOCK) {
         const uint64_t i = base + threadIdx.x;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n,
         if (exhaustive || !s.uses_bvh) {
             if (live) trace_exhaustive(s, o, d, t, id);
         } else {
-            coop_trace<false, SPH>(s, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+            coop_trace<false, SPH>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
         }
         if (live) {
             prim[i] = id;

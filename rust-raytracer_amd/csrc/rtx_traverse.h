@@ -150,6 +150,7 @@ struct TravStack {
     uint32_t steps = 0;   // diagnostic build: node steps of this lane
     uint32_t leaves = 0;  // diagnostic build: primitive tests of this lane
     unsigned long long t_mem = 0, t_alu = 0, t_don = 0;   // diagnostic build: shader cycles waiting for the fetch / computing / giving work
+    unsigned long long t_deq = 0, t_setup = 0;            // diagnostic build: shader cycles taking a work unit / setting up its rays
 #endif
     RTX_D void set(int* lds, const DevScene& s) {
         base = (RTX_LDS_PTR(int))lds + threadIdx.x;
@@ -267,22 +268,37 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
         const int ra = sw ? r[j] : r[i], rb_ = sw ? r[i] : r[j];  \
         t[i] = ta; t[j] = tb; r[i] = ra; r[j] = rb_;   \
     } while (0)
+    // Up to three children go to the stack. Their slots follow from the hit flags alone, so the common case -- the
+    // entries fit the LDS part of the stack -- is three predicated LDS writes to computed slots, with no test per push.
     if (SORT) {
         RTX_CE(0, 1); RTX_CE(2, 3); RTX_CE(0, 2); RTX_CE(1, 3); RTX_CE(1, 2);
-        if (t[3] < inf) st.put(sp++, r[3]);
-        if (t[2] < inf) st.put(sp++, r[2]);
-        if (t[1] < inf) st.put(sp++, r[1]);
+        const int h3 = t[3] < inf, h2 = t[2] < inf, h1 = t[1] < inf;   // sorted: a hit at k implies hits below k
+        if (sp + 3 <= RTX_STACK_LDS) {
+            if (h3) st.base[sp * RTX_BLOCK] = r[3];
+            if (h2) st.base[(sp + h3) * RTX_BLOCK] = r[2];
+            if (h1) st.base[(sp + h3 + h2) * RTX_BLOCK] = r[1];
+            sp += h3 + h2 + h1;
+        } else {
+            if (h3) st.put(sp++, r[3]);
+            if (h2) st.put(sp++, r[2]);
+            if (h1) st.put(sp++, r[1]);
+        }
         if (t[0] < inf) return r[0];
     } else {
-        int next = done;
-#pragma unroll
-        for (int k = 3; k >= 0; --k) {
-            if (t[k] < inf) {
-                if (next != done) st.put(sp++, next);
-                next = r[k];
-            }
+        // any order will do: the lowest hit child is next, the others are pushed from the highest down
+        const int h0 = t[0] < inf, h1 = t[1] < inf, h2 = t[2] < inf, h3 = t[3] < inf;
+        const int p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;   // pushed: hit, and not the lowest hit
+        if (sp + 3 <= RTX_STACK_LDS) {
+            if (p3) st.base[sp * RTX_BLOCK] = r[3];
+            if (p2) st.base[(sp + p3) * RTX_BLOCK] = r[2];
+            if (p1) st.base[(sp + p3 + p2) * RTX_BLOCK] = r[1];
+            sp += p3 + p2 + p1;
+        } else {
+            if (p3) st.put(sp++, r[3]);
+            if (p2) st.put(sp++, r[2]);
+            if (p1) st.put(sp++, r[1]);
         }
-        if (next != done) return next;
+        if (h0 | h1 | h2 | h3) return h0 ? r[0] : h1 ? r[1] : h2 ? r[2] : r[3];
     }
 #undef RTX_CE
     if (sp == bot) return done;
@@ -300,7 +316,38 @@ constexpr int kRefDone = 0x7fffffff;   // "no more work" reference (never a node
 struct Fetched {
     uint4 a, b, c, d;
 };
-RTX_D Fetched fetch_ref(const DevScene& s, int cur) {
+// The first RTX_TOP_NODES nodes of the tree -- its top levels: nodes are numbered in level order -- are copied into
+// LDS by every traversal workgroup. Every ray walks through them, and a wavefront's 64 divergent 64-byte fetches
+// occupy the CU's vector-memory path for ~125 cycles even when they all hit in L1 (four dwordx4 instructions, ~31
+// cycles each), which is what bounds these kernels; the same fetch from LDS is four ds_read_b128 (~16 cycles) with a
+// fraction of the latency. 320 nodes = 20 KiB: with the traversal stacks 39 KiB per workgroup, four workgroups per CU.
+#ifndef RTX_TOP_NODES
+#define RTX_TOP_NODES 320
+#endif
+typedef unsigned int rtx_u32x4 __attribute__((ext_vector_type(4)));
+struct TopCache {
+    RTX_LDS_PTR(rtx_u32x4) base;
+    uint32_t count;   // nodes cached (0: none, e.g. no tree)
+    // All threads of the workgroup call this before the first traversal step; `lds` holds RTX_TOP_NODES * 4 quads.
+    RTX_D void load(uint4* lds, const DevScene& s) {
+        base = (RTX_LDS_PTR(rtx_u32x4))lds;
+        count = s.uses_bvh ? min(s.n_nodes, (uint32_t)RTX_TOP_NODES) : 0u;
+        const uint4* src = reinterpret_cast<const uint4*>(s.nodes);
+        for (uint32_t k = threadIdx.x; k < count * 4u; k += RTX_BLOCK) lds[k] = src[k];
+        __syncthreads();
+    }
+};
+RTX_D Fetched fetch_ref(const DevScene& s, const TopCache& tc, int cur) {
+    if ((uint32_t)cur < tc.count) {   // an inner node of the cached top levels (leaf references are negative)
+        RTX_LDS_PTR(rtx_u32x4) q = tc.base + (uint32_t)cur * 4u;
+        const rtx_u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+        Fetched f;
+        f.a = make_uint4(a.x, a.y, a.z, a.w);
+        f.b = make_uint4(b.x, b.y, b.z, b.w);
+        f.c = make_uint4(c.x, c.y, c.z, c.w);
+        f.d = make_uint4(d.x, d.y, d.z, d.w);
+        return f;
+    }
     const uint4* p = (cur >= 0) ? reinterpret_cast<const uint4*>(s.nodes + cur)
                                 : reinterpret_cast<const uint4*>(s.recs + (~(uint32_t)cur >> 3));
     // Four 16-byte loads issued back to back and one wait, spelled out: left to itself the

@@ -31,6 +31,85 @@ __global__ void k_valu(float* out, int iters, unsigned long long* cyc) {
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// Issue cost of other VALU instructions the traversal kernels are made of, 4 waves per SIMD, independent chains.
+#define VALU_KERNEL(NAME, ASM)                                                                                    \
+    __global__ void NAME(float* out, int iters, unsigned long long* cyc) {                                        \
+        float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        const float b = 1.0001f, c = 0.5f;                                                                         \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                               \
+        for (int i = 0; i < iters; ++i) {                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                       \
+                asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                               \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                             : "v"(b), "v"(c) : "vcc");                                                          \
+            }                                                                                                      \
+        }                                                                                                          \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                               \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                       \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;            \
+    }
+#define A_ADD(k) "v_add_f32 %" #k ", %" #k ", %8\n\t"
+#define A_MUL(k) "v_mul_f32 %" #k ", %" #k ", %8\n\t"
+#define A_MAX3(k) "v_max3_f32 %" #k ", %" #k ", %8, %9\n\t"
+#define A_CND(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n\t"
+#define A_CMP(k) "v_cmp_lt_f32 vcc, %" #k ", %8\n\t"
+#define A_CMPS(k) "v_cmp_lt_f32 s[20:21], %" #k ", %8\n\t"
+#define A_CVT(k) "v_cvt_f32_ubyte1 %" #k ", %" #k "\n\t"
+#define A_AND(k) "v_and_b32 %" #k ", %" #k ", %8\n\t"
+#define A_LSH(k) "v_lshlrev_b32 %" #k ", 1, %" #k "\n\t"
+#define A_MOV(k) "v_mov_b32 %" #k ", %8\n\t"
+#define A_FMA(k) "v_fma_f32 %" #k ", %" #k ", %8, %9\n\t"
+#define A_RCP(k) "v_rcp_f32 %" #k ", %" #k "\n\t"
+#define A_CNDS(k) "v_cndmask_b32 %" #k ", %" #k ", %8, s[22:23]\n\t"
+VALU_KERNEL(k_add, A_ADD)
+VALU_KERNEL(k_mul, A_MUL)
+VALU_KERNEL(k_max3, A_MAX3)
+VALU_KERNEL(k_cnd, A_CND)
+VALU_KERNEL(k_cmp, A_CMP)
+VALU_KERNEL(k_cvt, A_CVT)
+VALU_KERNEL(k_and, A_AND)
+VALU_KERNEL(k_lsh, A_LSH)
+VALU_KERNEL(k_mov, A_MOV)
+VALU_KERNEL(k_fma, A_FMA)
+VALU_KERNEL(k_rcp, A_RCP)
+#define A_MAX(k) "v_max_f32 %" #k ", %" #k ", %8\n\t"
+#define A_PAIR(k) "v_cmp_lt_f32 vcc, %" #k ", %9\n\tv_cndmask_b32 %" #k ", %" #k ", %8, vcc\n\t"
+#define A_CNDZ(k) "v_cndmask_b32 %" #k ", %8, %9, vcc\n\t"
+VALU_KERNEL(k_max, A_MAX)
+VALU_KERNEL(k_pair, A_PAIR)
+VALU_KERNEL(k_cndz, A_CNDZ)
+__global__ void k_cnds(float* out, int iters, unsigned long long* cyc) {   // select on an SGPR pair (VOP3 form)
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float b = 1.0001f, c = 0.5f;
+    asm volatile("s_mov_b64 s[22:23], 0x55555555" ::: "s22", "s23");
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            asm volatile(A_CNDS(0) A_CNDS(1) A_CNDS(2) A_CNDS(3) A_CNDS(4) A_CNDS(5) A_CNDS(6) A_CNDS(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s22", "s23");
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+__global__ void k_cmps(float* out, int iters, unsigned long long* cyc) {   // compare into an SGPR pair, then a select that reads one
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float b = 1.0001f, c = 0.5f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            asm volatile(A_CMPS(0) A_CMPS(1) A_CMPS(2) A_CMPS(3) A_CMPS(4) A_CMPS(5) A_CMPS(6) A_CMPS(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s20", "s21");
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
 // mode 0: 4 x dwordx4 per lane (64 B record), 1: 2 x dwordx4, 2: 1 x dwordx4, 3: mode 0 with odd lanes idle,
 // 4: four adjacent lanes fetch the four quarters of ONE record (one dwordx4 each; 16 records per wave-instruction)
 // 5: mode 0 with the records of a wave's lanes adjacent in memory (coherent rays)
@@ -144,6 +223,26 @@ int main() {
         const int waves_per_simd = threads / 256;
         printf("VALU: %d wave(s) per SIMD: %.2f cycles per v_fma_f32 per wave, %.2f cycles of the SIMD per wave-instruction\n", waves_per_simd,
                per_wave, per_wave / waves_per_simd);
+    }
+    {
+        struct { const char* name; void (*fn)(float*, int, unsigned long long*); } ops[] = {
+            {"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_mul_f32", k_mul}, {"v_max3_f32", k_max3}, {"v_cndmask_b32 (vcc)", k_cnd},
+            {"v_cmp_lt_f32 -> vcc", k_cmp}, {"v_cmp_lt_f32 -> sgpr pair", k_cmps}, {"v_cvt_f32_ubyte1", k_cvt}, {"v_and_b32", k_and},
+            {"v_lshlrev_b32", k_lsh}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_max_f32", k_max},
+            {"v_cmp + v_cndmask pair (per pair)", k_pair}, {"v_cndmask_b32 no dep on dst", k_cndz}, {"v_cndmask_b32 (sgpr pair)", k_cnds}};
+        for (auto& op : ops) {
+            for (int threads : {256, 1024}) {
+                for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(op.fn, dim3(cus), dim3(threads), 0, 0, out, 4000, cyc);
+                CHECK(hipDeviceSynchronize());
+                std::vector<unsigned long long> h((size_t)cus * threads / 64);
+                CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                double sum = 0;
+                for (auto v : h) sum += (double)v;
+                const double per_wave = sum / h.size() / (4000.0 * 64);
+                printf("VALU op %-28s %d wave(s)/SIMD: %.2f cycles per instruction per wave, %.2f of the SIMD\n", op.name, threads / 256, per_wave,
+                       per_wave / (threads / 256));
+            }
+        }
     }
     // ---- 2. dependent gathers ----
     for (size_t kb : {16, 1024, 24 * 1024, 192 * 1024, 2048 * 1024}) {

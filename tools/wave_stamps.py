@@ -33,15 +33,24 @@ def summarize(name, rec):
     span = end.max()
     prof = None
     if step_sum.sum() or (rec[:, 3] >> 21).any():   # diagnostic build: rec[3] holds the cycle split (units of 256 shader cycles)
-        t_mem = (rec[:, 3] & 0x1fffff).astype(np.float64) * 256
-        t_alu = ((rec[:, 3] >> 21) & 0x1fffff).astype(np.float64) * 256
-        t_don = ((rec[:, 3] >> 42) & 0x1fffff).astype(np.float64) * 256
+        if name == "k_shadow":     # five 12-bit shares: fetch wait, compute, giving work, taking units, ray set-up
+            t_mem = (rec[:, 3] & 0xfff).astype(np.float64) * 256
+            t_alu = ((rec[:, 3] >> 12) & 0xfff).astype(np.float64) * 256
+            t_don = ((rec[:, 3] >> 24) & 0xfff).astype(np.float64) * 256
+            t_deq = ((rec[:, 3] >> 36) & 0xfff).astype(np.float64) * 256
+            t_setup = ((rec[:, 3] >> 48) & 0xfff).astype(np.float64) * 256
+        else:
+            t_mem = (rec[:, 3] & 0x1fffff).astype(np.float64) * 256
+            t_alu = ((rec[:, 3] >> 21) & 0x1fffff).astype(np.float64) * 256
+            t_don = ((rec[:, 3] >> 42) & 0x1fffff).astype(np.float64) * 256
+            t_deq = t_setup = t_mem * 0
         life = (end - start) * 1e-6                          # seconds
         tot = t_mem + t_alu + t_don
         ghz = tot.sum() / life.sum() / 1e9                   # lower bound of the shader clock: cycles accounted per second of life
         last = np.argsort(end)[-64:]
         prof = {"mem_wait_share": float(t_mem.sum() / tot.sum()), "compute_share": float(t_alu.sum() / tot.sum()),
                 "donation_share": float(t_don.sum() / tot.sum()), "accounted_gcycles_per_s": float(ghz),
+                "dequeue_gcycles_per_s": float(t_deq.sum() / life.sum() / 1e9), "setup_gcycles_per_s": float(t_setup.sum() / life.sum() / 1e9),
                 "last64_waves": {"mem_wait_share": float(t_mem[last].sum() / tot[last].sum()),
                                  "compute_share": float(t_alu[last].sum() / tot[last].sum()),
                                  "donation_share": float(t_don[last].sum() / tot[last].sum()),
