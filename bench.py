@@ -480,11 +480,11 @@ def main():
                 "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray,
                 "algorithmic_GBps": algorithmic, "algorithmic_frac": algorithmic / HBM_PEAK_GBS,
                 "traffic_over_algorithmic": (traffic / (rays_per_launch * b_ray)) if (traffic and rays_per_launch) else None,
-                "device_copy_GBps": copy_gbs, "source_hash": src_hash,
+                "device_copy_GBps": copy_gbs, "source_hash": src_hash, "workload_key": workload_key,
                 "counters_from": ("profiles/pmc_traffic.json[%s], same source hash" % workload_key) if pmc else None}
         if pmc:
-            for k in ("lane_utilisation", "valu_issue_frac", "valu_instructions_per_launch", "fetch_iterations_per_launch",
-                      "l2_hit_rate", "l1_hit_rate", "l1_miss_latency_cycles", "ta_busy_frac", "wave_wait_frac"):
+            for k in ("lane_utilisation", "valu_issue_frac", "valu_instructions_per_launch",
+                      "fetch_iterations_per_launch", "l2_hit_rate", "l1_hit_rate", "l1_miss_latency_cycles", "ta_busy_frac", "wave_wait_frac"):
                 if k in pmc:
                     roof[k] = pmc[k]
             roof["limiter"] = ("VALU issue and dependent-fetch latency, not HBM: HBM-side traffic is %.0f %% of the algorithmic bytes"
