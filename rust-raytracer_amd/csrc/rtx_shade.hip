@@ -202,7 +202,10 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(PrimaryGen pg, Work wk, ui
 // Costs are kept per GROUP of 8 consecutive units (neighbouring tiles cost about the same):
 // sorting a frame's few thousand groups takes one small workgroup a few microseconds, and a
 // group stays together on one shard, which keeps its nodes in one XCD's L2.
-constexpr uint32_t kGroupLog2 = 3, kGroup = 1u << kGroupLog2;
+#ifndef RTX_GROUP_LOG2
+#define RTX_GROUP_LOG2 3
+#endif
+constexpr uint32_t kGroupLog2 = RTX_GROUP_LOG2, kGroup = 1u << kGroupLog2;
 struct UnitOrder {
     uint32_t n_cost;    // unit count of the launch that last added to cost[] (0: none, or too many for cap)
     uint32_t n_order;   // unit count whose groups order[] is a permutation of (0: none)
@@ -232,7 +235,7 @@ struct UnitQueue {
     }
     RTX_D void record(uint32_t unit, unsigned long long t0) {
         if (uo && (threadIdx.x & 63) == 0 && (unit >> kGroupLog2) < uo->cap)
-            atomicAdd(&uo->cost()[unit >> kGroupLog2], (uint32_t)(wall_clock64() - t0));
+            atomicMax(&uo->cost()[unit >> kGroupLog2], (uint32_t)(wall_clock64() - t0));   // a group is as urgent as its slowest unit: its units go out together
     }
     // Wave-uniform: next unit for this wavefront, or 0xffffffff when every shard is empty.
     RTX_D uint32_t next() {
