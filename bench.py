@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="with one process: run the multi-GPU code path (process group of one rank, tile slab, all-gather, "
                          "assembly) instead of the single-GPU one; for checking that path on a one-GPU box")
+    ap.add_argument("--frames-per-batch", type=int, default=0,
+                    help="frames rendered as one set of launches (rtx_render_frames_async); 0 = 4 per GPU for the 1080p "
+                         "configuration (so that a rank's share of a batch is as much work as four whole frames), 1 otherwise")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -259,16 +262,28 @@ def main():
     ctxs = [ctx] + [ctx.clone() for _ in range(n_contexts - 1)]
     w, h = args.width, args.height
     tpr = rtx.tiles_per_rank(w, h, world)
+    # Frames per batch: a rank's 1/N share of one small frame cannot fill a GPU (its launches are as long as their
+    # longest ray chains however few rays they hold), so sharded runs render the shares of several frames at once.
+    # Larger launches also lose less at their ends (a launch finishes with its slowest wavefronts while the rest of the
+    # GPU idles), so the 1080p configuration renders 4 frames per batch and GPU -- measured 8.2 / 9.9 / 10.8 / 11.0
+    # Grays/s with 1 / 2 / 4 / 8 frames per batch on one GPU. The 4K and 8K configurations render frame by frame.
+    if args.frames_per_batch > 0:
+        fpb = args.frames_per_batch
+    elif args.config == 3:
+        fpb = min(4 * world, rtx.MAX_BATCH_FRAMES)
+    else:
+        fpb = 1
+    fps = (fps + fpb - 1) // fpb * fpb      # a step is a whole number of batches
     # Frames are pipelined: while the GPU renders frame k the host collects frame k - 1 (and, for
     # N > 1, its slabs travel while frame k renders and frame k - 2 is assembled). Every frame that
     # was enqueued inside the timed region is complete before the clock stops.
     in_flight = max(1, len(ctxs))     # frames enqueued beyond the one being collected
     # (sharded runs: two slabs per context, so that a context's recorded frames see the same two buffers again)
     ring = 2 * len(ctxs) if multi else in_flight + 2
-    images = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
-    slabs = [torch.zeros(tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
-    gathered = [torch.zeros(world * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
-    gathered_host = torch.zeros(world * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
+    images = [torch.zeros(fpb * h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
+    slabs = [torch.zeros(fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
+    gathered = [torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
+    gathered_host = torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
     image = images[0]
     acc = {}
     gather_wait = [0.0]   # seconds the host waited for slabs that had not arrived when they were needed
@@ -315,7 +330,10 @@ def main():
         ev.record()
         gather_done[idx] = ev
         lib_streams[0].wait_event(ev)                   # ... and so does the stream that assembles
-        ctx.assemble_tiles_async(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+        if fpb > 1:
+            ctx.assemble_frames_async(fpb, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+        else:
+            ctx.assemble_tiles_async(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
         ev2 = event_pool[idx][1]
         ev2.record(lib_streams[0])
         assemble_done[idx] = ev2
@@ -328,25 +346,30 @@ def main():
         state["collected"] += 1
         if not multi:
             return
-        if abi:      # gather-to-root and assembly inside the library; rank 0 ends up with the image
-            ctx.gather_frame(w, h, slabs[idx].data_ptr(), image.data_ptr(), 0)
+        if abi:      # gather-to-root and assembly inside the library; rank 0 ends up with the image(s)
+            for f in range(fpb):
+                ctx.gather_frame(w, h, slabs[idx].data_ptr() + f * tpr * 192, image.data_ptr() + f * h * w * 3, 0)
             return
         if gloo:
             dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
             gathered[idx].copy_(gathered_host)
             torch.cuda.current_stream().synchronize()
-            ctx.assemble_tiles(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+            ctx.assemble_frames_async(fpb, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+            torch.cuda.ExternalStream(ctx.stream(), device=dev).synchronize()
             return
         finish_gather()            # the frame before it
         if assemble_done[idx] is not None:              # the assembly that last read this gather buffer
             torch.cuda.current_stream().wait_event(assemble_done[idx])
         state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
 
-    def step():     # one frame; a bench step is `fps` of them
+    def step():     # one batch of `fpb` frames; a bench step is `fps` frames
         k = state["enqueued"]
         state["enqueued"] += 1
-        if not multi:   # single GPU: the frame is written row-major in place
-            ctxs[k % len(ctxs)].render_device_async(w, h, args.depth, 10, images[k % len(images)].data_ptr())
+        if not multi:   # single GPU: the frames are written row-major in place
+            if fpb > 1:
+                ctxs[k % len(ctxs)].render_frames_async(fpb, None, w, h, args.depth, 10, 0, 1, images[k % len(images)].data_ptr(), True)
+            else:
+                ctxs[k % len(ctxs)].render_device_async(w, h, args.depth, 10, images[k % len(images)].data_ptr())
         else:
             if lib_streams is not None and gather_done[k % ring] is not None:   # the all-gather that last read this slab
                 lib_streams[k % len(ctxs)].wait_event(gather_done[k % ring])
@@ -358,7 +381,10 @@ def main():
             if timing_state[c] != timed:
                 ctxs[c].set_option("kernel_timing", timed)
                 timing_state[c] = timed
-            ctxs[k % len(ctxs)].render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
+            if fpb > 1:
+                ctxs[c].render_frames_async(fpb, None, w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr(), False)
+            else:
+                ctxs[c].render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
         if state["enqueued"] - state["collected"] > in_flight:
             collect()
 
@@ -376,14 +402,14 @@ def main():
         for _ in range(3 * ring):
             step()
         sync()
-    for _ in range(args.warmup * fps):
+    for _ in range(args.warmup * fps // fpb):
         step()
     sync()
     reset_acc()
-    state["timed_base"] = state["enqueued"]      # the first frame of the timed region carries timing events
+    state["timed_base"] = state["enqueued"]      # the first batch of the timed region carries timing events
     n_frames = args.steps * fps
     t0 = time.perf_counter()
-    for _ in range(n_frames):
+    for _ in range(n_frames // fpb):
         step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -402,7 +428,7 @@ def main():
         whole = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
         ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
         torch.cuda.synchronize()
-        sharded_equal = bool(torch.equal(whole, image))
+        sharded_equal = all(bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3])) for f in range(fpb))
     gather_isolated_ms = None
     if abi:                    # the exchange step alone: 10 gathers to the root, nothing else on the GPU
         torch.cuda.synchronize()
@@ -440,6 +466,8 @@ def main():
         # sources and with the workload it was collected on); anything else is not quoted.
         pmc = None
         workload_key = "config%d_grid%d_%dx%d_depth%d_spec%g_glass%d" % (args.config, args.grid, w, h, args.depth, args.spec, args.glass)
+        if fpb > 1:
+            workload_key += "_fpb%d" % fpb      # counters per launch belong to a launch of that many frames
         default_workload = (args.config == 3 and args.grid == 708 and (w, h) == (1920, 1080) and args.depth == 10
                             and args.spec == 0.0 and args.glass == 0 and not multi)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -512,11 +540,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "synthetic %d-triangle tessellated height field%s + 4 point lights at %dx%d, depth %d, "
-                                   "LBVH traversal, scene and BVH resident in HBM; one step = %d frames"
-                                   % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps),
+                                   "LBVH traversal, scene and BVH resident in HBM; one step = %d frames, rendered %d per set of launches"
+                                   % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps, fpb),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth, "frames_per_step": fps,
+                       "frames_per_batch": fpb, "batch_latency_ms_approx": elapsed / frames * 1e3 * fpb * (len(ctxs) + 1),
                        "parallelism": ("tile-sharded x%d (%s, %s collectives)" % (world, args.backend, args.collectives)) if multi else "single GPU",
-                       "ranks": world, "frames_in_flight_per_gpu": len(ctxs) + 1},
+                       "ranks": world, "batches_in_flight_per_gpu": len(ctxs) + 1},
             "ms_per_frame": elapsed / frames * 1e3,
             "rays_per_frame": total_traced / frames,
             "primary_hit_fraction": (acc["shaded_primary"] / acc["primary"]) if acc.get("primary") else None,
@@ -534,9 +563,9 @@ def main():
             "roofline": roof,
         }
         if default_workload and len(ctxs) == 1 and not args.no_extras:
-            # Supplementary, outside the timed region and not `value`: the same frames alternating between three
-            # contexts (streams), where one frame's kernel tails overlap the next frame's kernels. The headline run
-            # uses one context so that its per-kernel times are those of kernels running alone.
+            # Supplementary, outside the timed region and not `value`: the same frames rendered one per set of launches
+            # (the configuration the headline used before frames were batched), on one context and alternating between
+            # three contexts (streams), where one frame's kernel tails overlap the next frame's kernels.
             try:
                 extra = [ctx.clone(), ctx.clone()]    # share the scene and the BVH, own stream and workspace
                 for c in extra:
@@ -544,6 +573,26 @@ def main():
                 ctx.set_option("kernel_timing", 0)
                 trio = [ctx] + extra
                 bufs = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(6)]
+
+                def run1(n):      # frame by frame on one context, two frames in flight: the configuration of earlier rounds
+                    ms = [0.0, 0.0, 0]
+                    for k in range(n):
+                        if k >= 2:
+                            st1 = ctx.render_wait()
+                            ms[0] += st1.closest_ms; ms[1] += st1.shadow_ms; ms[2] += 1
+                        ctx.render_device_async(w, h, args.depth, 10, bufs[k % 3].data_ptr())
+                    for _ in range(2):
+                        ctx.render_wait()
+                    torch.cuda.synchronize()
+                    return ms
+                ctx.set_option("kernel_timing", 1)
+                run1(12)
+                t1 = time.perf_counter()
+                ms1 = run1(300)
+                dt1 = (time.perf_counter() - t1) / 300
+                ctx.set_option("kernel_timing", 0)
+                single = {"ms_per_frame": dt1 * 1e3, "Mrays_s": (total_traced / frames) / dt1 / 1e6,
+                          "closest_ms": ms1[0] / max(ms1[2], 1), "shadow_ms": ms1[1] / max(ms1[2], 1)}
 
                 def run3(n):
                     for k in range(n):
@@ -557,9 +606,10 @@ def main():
                 t3 = time.perf_counter()
                 run3(300)
                 dt3 = (time.perf_counter() - t3) / 300
-                out["supplementary"] = {"three_contexts_ms_per_frame": dt3 * 1e3,
+                out["supplementary"] = {"frame_by_frame_one_context": single,
+                                        "three_contexts_ms_per_frame": dt3 * 1e3,
                                         "three_contexts_Mrays_s": (total_traced / frames) / dt3 / 1e6,
-                                        "frame_equals_headline_frame": bool(torch.equal(bufs[299 % 6], image))}
+                                        "frame_equals_headline_frame": bool(torch.equal(bufs[299 % 6], image[:h * w * 3]))}
                 ctx.set_option("kernel_timing", 1)
                 for c in extra:
                     c.close()

@@ -273,6 +273,29 @@ int rtx_assemble_tiles(rtx_context* ctx, uint32_t width, uint32_t height, uint32
 int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, uint32_t world,
                              const uint8_t* d_slabs, uint8_t* d_rgb);
 
+/* Batches of frames (no counterpart in the reference, which renders one frame per process; for callers that render
+ * a camera path over one scene, and for tile-sharded rendering, where one rank's share of one frame is too little
+ * work to fill a GPU). n_frames (1 .. RTX_MAX_BATCH_FRAMES) frames of the same size are rendered as ONE set of
+ * launches: frame f uses cameras[f] (RayTracer::setup_camera per frame, src/lib.rs:69-84), or the scene's camera
+ * for every frame when cameras is NULL. Each frame's pixels are exactly those of a separate rtx_render_device /
+ * rtx_render_tiles call with that camera (area-light draws are keyed by pixel and do not depend on the batch).
+ *   row_major != 0 (world must be 1): d_out receives [n_frames][h][w][3];
+ *   otherwise d_out receives the rank's slabs, [n_frames][rtx_tiles_per_rank()][8*8*3].
+ * All frames' rays must fit one ray batch (the "batch_pixels" option, default 16 Mi rays): RTX_ERR_INVALID_ARG
+ * otherwise. The _async form enqueues and returns like rtx_render_tiles_async; rtx_render_wait collects the batch
+ * (ray counts are totals over its frames). */
+#define RTX_MAX_BATCH_FRAMES 32u
+int rtx_render_frames(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width, uint32_t height,
+                      uint32_t depth, uint32_t samples, uint32_t rank, uint32_t world, uint8_t* d_out, int row_major,
+                      rtx_render_stats* stats);
+int rtx_render_frames_async(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width,
+                            uint32_t height, uint32_t depth, uint32_t samples, uint32_t rank, uint32_t world,
+                            uint8_t* d_out, int row_major);
+/* Gathered slabs of a batch, [world][n_frames][tiles_per_rank][8*8*3] (an all-gather of the ranks' d_out), into
+ * [n_frames][h][w][3]; enqueued on rtx_stream like rtx_assemble_tiles_async. */
+int rtx_assemble_frames_async(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint32_t height, uint32_t world,
+                              const uint8_t* d_slabs, uint8_t* d_rgb);
+
 /* ---- exchange steps of a tile-sharded frame (no counterpart in the reference, which has no second device) -----
  * One process per GPU, one context per process. The scene is replicated once from a root rank into every rank's
  * HBM; every frame, each rank renders its interleaved tiles (rtx_render_tiles) and the slabs are gathered to the

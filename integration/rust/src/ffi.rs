@@ -22,6 +22,7 @@ pub const RTX_TRI_VERTEX_NORMAL: u8 = 1;
 pub const RTX_TRI_VERTEX_MATERIAL: u8 = 2;
 pub const RTX_NOALLOC_MAX_RAYS: u64 = 1 << 26;
 pub const RTX_COMM_ID_BYTES: usize = 128;
+pub const RTX_MAX_BATCH_FRAMES: u32 = 32;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -143,6 +144,14 @@ extern "C" {
                               d_rgb: *mut u8) -> c_int;
     pub fn rtx_assemble_tiles_async(ctx: *mut rtx_context, width: u32, height: u32, world: u32, d_slabs: *const u8,
                                     d_rgb: *mut u8) -> c_int;
+    pub fn rtx_render_frames(ctx: *mut rtx_context, n_frames: u32, cameras: *const rtx_camera, width: u32, height: u32,
+                             depth: u32, samples: u32, rank: u32, world: u32, d_out: *mut u8, row_major: c_int,
+                             stats: *mut rtx_render_stats) -> c_int;
+    pub fn rtx_render_frames_async(ctx: *mut rtx_context, n_frames: u32, cameras: *const rtx_camera, width: u32,
+                                   height: u32, depth: u32, samples: u32, rank: u32, world: u32, d_out: *mut u8,
+                                   row_major: c_int) -> c_int;
+    pub fn rtx_assemble_frames_async(ctx: *mut rtx_context, n_frames: u32, width: u32, height: u32, world: u32,
+                                     d_slabs: *const u8, d_rgb: *mut u8) -> c_int;
     pub fn rtx_comm_unique_id(id128: *mut u8) -> c_int;
     pub fn rtx_comm_init(ctx: *mut rtx_context, rank: u32, world: u32, id128: *const u8) -> c_int;
     pub fn rtx_comm_destroy(ctx: *mut rtx_context) -> c_int;

@@ -37,7 +37,9 @@ EXPORTED_SYMBOLS = [
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
     "rtx_intersect_batch_device_noalloc", "rtx_scene_set_device", "rtx_clone",
     "rtx_comm_unique_id", "rtx_comm_init", "rtx_comm_destroy", "rtx_scene_broadcast", "rtx_gather_frame",
+    "rtx_render_frames", "rtx_render_frames_async", "rtx_assemble_frames_async",
 ]
+MAX_BATCH_FRAMES = 32
 
 
 class RtxError(RuntimeError):
@@ -155,6 +157,9 @@ def lib():
         L.rtx_render_device_async.argtypes = [vp, u32, u32, u32, u32, vp]
         L.rtx_render_tiles_async.argtypes = [vp, u32, u32, u32, u32, u32, u32, vp]
         L.rtx_render_wait.argtypes = [vp, C.POINTER(RenderStats)]
+        L.rtx_render_frames.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32, vp, C.c_int, C.POINTER(RenderStats)]
+        L.rtx_render_frames_async.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u32, vp, C.c_int]
+        L.rtx_assemble_frames_async.argtypes = [vp, u32, u32, u32, u32, vp, vp]
         L.rtx_comm_unique_id.argtypes = [vp]
         L.rtx_comm_init.argtypes = [vp, u32, u32, vp]
         L.rtx_comm_destroy.argtypes = [vp]
@@ -462,6 +467,34 @@ class Context:
     def assemble_tiles_async(self, width, height, world, d_slabs, d_rgb):
         """Enqueues the assembly on the context's stream (see stream()) and returns."""
         self._check(self._L.rtx_assemble_tiles_async(self._h, width, height, world, d_slabs, d_rgb))
+
+    @staticmethod
+    def _camera_array(n_frames, cameras):
+        """cameras: None (the scene's camera for every frame) or a sequence of n_frames Camera structs."""
+        if cameras is None:
+            return None, None
+        if len(cameras) != n_frames:
+            raise ValueError("one camera per frame")
+        arr = (Camera * n_frames)(*cameras)
+        return arr, C.cast(arr, C.c_void_p)
+
+    def render_frames(self, n_frames, cameras, width, height, depth, samples, rank, world, d_out, row_major):
+        """A batch of frames in one set of launches (rtx_render_frames); d_out: device pointer to the frames' images
+        (row_major, world 1) or to the frames' tile slabs."""
+        keep, ptr = self._camera_array(n_frames, cameras)
+        st = RenderStats()
+        self._check(self._L.rtx_render_frames(self._h, n_frames, ptr, width, height, depth, samples, rank, world, d_out,
+                                              1 if row_major else 0, C.byref(st)))
+        return st
+
+    def render_frames_async(self, n_frames, cameras, width, height, depth, samples, rank, world, d_out, row_major):
+        """Enqueues a batch of frames; collect it with render_wait()."""
+        keep, ptr = self._camera_array(n_frames, cameras)
+        self._check(self._L.rtx_render_frames_async(self._h, n_frames, ptr, width, height, depth, samples, rank, world, d_out,
+                                                    1 if row_major else 0))
+
+    def assemble_frames_async(self, n_frames, width, height, world, d_slabs, d_rgb):
+        self._check(self._L.rtx_assemble_frames_async(self._h, n_frames, width, height, world, d_slabs, d_rgb))
 
 
 def comm_unique_id():

@@ -134,6 +134,7 @@ void rtx_destroy(rtx_context* ctx) {
     for (auto& slot : ctx->async_slots)
         for (hipEvent_t e : slot.events) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->cam_dev) (void)hipFree(ctx->cam_dev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -499,6 +500,42 @@ int rtx_render_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, ui
     if (world == 0 || rank >= world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rank must be below world");
     if (!d_rgb_tiles) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_rgb_tiles is NULL");
     return rtx_render_async_impl(ctx, width, height, depth, samples, rank, world, d_rgb_tiles, false);
+}
+
+static int check_frames(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint32_t height, uint32_t rank, uint32_t world,
+                        const uint8_t* d_out, int row_major) {
+    int rc = check_ready(ctx);
+    if (rc != RTX_OK) return rc;
+    if (n_frames == 0 || n_frames > RTX_MAX_BATCH_FRAMES) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "n_frames must be 1 .. RTX_MAX_BATCH_FRAMES");
+    if (width == 0 || height == 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "zero image size");
+    if (world == 0 || rank >= world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rank must be below world");
+    if (row_major && world != 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "row-major output needs world == 1");
+    if (!d_out) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "d_out is NULL");
+    return RTX_OK;
+}
+
+int rtx_render_frames(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width, uint32_t height,
+                      uint32_t depth, uint32_t samples, uint32_t rank, uint32_t world, uint8_t* d_out, int row_major,
+                      rtx_render_stats* stats) {
+    const int rc = check_frames(ctx, n_frames, width, height, rank, world, d_out, row_major);
+    if (rc != RTX_OK) return rc;
+    return rtx_render_impl(ctx, width, height, depth, samples, rank, world, d_out, stats, row_major != 0, -1, n_frames, cameras);
+}
+
+int rtx_render_frames_async(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width, uint32_t height,
+                            uint32_t depth, uint32_t samples, uint32_t rank, uint32_t world, uint8_t* d_out, int row_major) {
+    const int rc = check_frames(ctx, n_frames, width, height, rank, world, d_out, row_major);
+    if (rc != RTX_OK) return rc;
+    return rtx_render_async_impl(ctx, width, height, depth, samples, rank, world, d_out, row_major != 0, n_frames, cameras);
+}
+
+int rtx_assemble_frames_async(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint32_t height, uint32_t world,
+                              const uint8_t* d_slabs, uint8_t* d_rgb) {
+    if (!ctx) return RTX_ERR_INVALID_ARG;
+    if (n_frames == 0 || n_frames > RTX_MAX_BATCH_FRAMES || width == 0 || height == 0 || world == 0 || !d_slabs || !d_rgb)
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "bad argument");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    return rtx_assemble_impl(ctx, width, height, world, d_slabs, d_rgb, n_frames);
 }
 
 int rtx_render_wait(rtx_context* ctx, rtx_render_stats* stats) {

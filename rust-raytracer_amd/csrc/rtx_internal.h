@@ -149,7 +149,8 @@ struct rtx_context {
 
     std::vector<char> work_blob;  // the Work struct of rtx_shade.hip describing work_allocs
     std::vector<hipEvent_t> events;
-    void* pinned = nullptr;       // page-locked staging for counter read-backs
+    void* pinned = nullptr;       // page-locked staging for counter read-backs and the cameras of a batch of frames
+    void* cam_dev = nullptr;      // device copy of those cameras (a page for the synchronous path, one per frame in flight)
     bool has_secondary = false;   // some material reflects or refracts (src/lib.rs:230,241)
 
     // knobs (rtx_set_option)
@@ -180,6 +181,8 @@ struct rtx_context {
         uint32_t w = 0, h = 0, depth = 0, samples = 0, rank = 0, world = 1;
         uint8_t* out = nullptr;
         bool direct = false;
+        uint32_t n_frames = 1;
+        std::vector<rtx_camera> cameras;          // empty: the scene's camera
     };
     AsyncSlot async_slots[2];
     uint32_t async_head = 0, async_count = 0;     // oldest slot, frames waiting
@@ -219,12 +222,15 @@ int rtx_noalloc_init_device(int device, std::string* err);   // once per device,
 int rtx_launch_intersect_noalloc(rtx_context* ctx, uint64_t n, const float* d_ori3, const float* d_dir3,
                                  int32_t* d_prim, float* d_t);
 // rtx_shade.hip
+// n_frames > 1: a batch of frames rendered as one set of launches, one camera each (cameras[n_frames]; nullptr: the
+// scene's camera); the output holds the frames' images, or the frames' tile slabs, one after the other.
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
                     uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct,
-                    int async_slot = -1);
+                    int async_slot = -1, uint32_t n_frames = 1, const rtx_camera* cameras = nullptr);
 int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples,
-                          uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, bool direct);
+                          uint32_t rank, uint32_t world, uint8_t* d_rgb_tiles, bool direct, uint32_t n_frames = 1,
+                          const rtx_camera* cameras = nullptr);
 void rtx_clear_graphs(rtx_context* ctx);   // after anything that changes what a recorded frame would launch
 int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats);
 int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, float* d_t, float* d_dir);
-int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb);
+int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb, uint32_t n_frames = 1);

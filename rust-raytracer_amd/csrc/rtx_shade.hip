@@ -62,6 +62,7 @@ struct Work {
 // Where a level-0 link (ray index of the rank) lies in the image.
 struct PixMap {
     uint32_t level0, rank, world, tiles_x, width;
+    uint32_t frames, rays_per_frame;   // a batch of several frames: link = frame * rays_per_frame + the frame's ray index
 };
 RTX_D uint32_t first_slot(const DevLight& l, uint32_t j, uint32_t n_samples) { return j + l.area_before * (n_samples - 1u); }
 
@@ -157,12 +158,22 @@ struct PrimaryGen {
     uint64_t first;
     uint32_t rank, world, tiles_x, n_tiles;
     uint32_t enabled;
+    // A batch of `frames` > 1 frames (one camera each, cams[frames] in device memory): ray g belongs to frame
+    // g / rays_per_frame; rays_per_frame is the same multiple of 64 on every rank (tiles_per_rank * 64).
+    uint32_t frames, rays_per_frame;
+    const CamSetup* cams;
 };
 RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4) {
-    const CamSetup& cam = pg.cam;
     const uint64_t g = pg.first + i;
-    const uint64_t tile = (g >> 6) * pg.world + pg.rank;
-    const uint32_t lane = (uint32_t)(g & 63);
+    uint64_t gl = g;
+    uint32_t frame = 0;
+    if (pg.frames > 1) {   // first == 0 and g < 2^32 (checked by the host)
+        frame = (uint32_t)g / pg.rays_per_frame;
+        gl = (uint32_t)g - frame * pg.rays_per_frame;
+    }
+    const CamSetup& cam = (pg.frames > 1) ? pg.cams[frame] : pg.cam;
+    const uint64_t tile = (gl >> 6) * pg.world + pg.rank;
+    const uint32_t lane = (uint32_t)(gl & 63);
     const uint32_t x = (uint32_t)(tile % pg.tiles_x) * RTX_TILE + (lane & 7u);
     const uint32_t y = (uint32_t)(tile / pg.tiles_x) * RTX_TILE + (lane >> 3);
     const bool valid = tile < pg.n_tiles && x < cam.w && y < cam.h;
@@ -442,11 +453,20 @@ struct OutMap {
     uint8_t* rgb;
     uint32_t direct_w;   // 0: tile slab; otherwise the image width (row-major output)
     uint32_t tiles_x;
+    // a batch of several frames: slabs follow each other at rays_per_frame pixels (so a link is its own slab index),
+    // row-major images at frame_pixels
+    uint32_t frames, rays_per_frame, frame_pixels;
     RTX_D size_t pixel(uint32_t link) const {
         if (!direct_w) return link;
+        size_t base = 0;
+        if (frames > 1) {
+            const uint32_t frame = link / rays_per_frame;
+            link -= frame * rays_per_frame;
+            base = (size_t)frame * frame_pixels;
+        }
         const uint32_t tile = link >> 6, lane = link & 63u;
         const uint32_t x = (tile % tiles_x) * RTX_TILE + (lane & 7u), y = (tile / tiles_x) * RTX_TILE + (lane >> 3);
-        return (size_t)y * direct_w + x;
+        return base + (size_t)y * direct_w + x;
     }
 };
 // `direct + ambient + reflective + refractive` (lib.rs:254) with reflective = ks * child
@@ -579,7 +599,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
                 const uint32_t link = f2u(o4.w);
                 uint64_t key;
                 if (pm.level0) {
-                    const uint32_t tile = (link >> 6) * pm.world + pm.rank, ln = link & 63u;
+                    const uint32_t fl = (pm.frames > 1) ? link % pm.rays_per_frame : link;   // the key names the pixel, not the frame
+                    const uint32_t tile = (fl >> 6) * pm.world + pm.rank, ln = fl & 63u;
                     const uint32_t x = (tile % pm.tiles_x) * RTX_TILE + (ln & 7u), y = (tile / pm.tiles_x) * RTX_TILE + (ln >> 3);
                     key = rng_mix64((uint64_t)y * pm.width + x);
                 } else {
@@ -933,15 +954,16 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_combine(DevScene s, Work wk, uint
     }
 }
 
-// Gathered slabs [world][tiles_per_rank][64][3] -> row-major image.
+// Gathered slabs [world][frames][tiles_per_rank][64][3] -> row-major images [frames][h][w][3].
 __global__ __launch_bounds__(RTX_BLOCK) void k_assemble(uint32_t w, uint32_t h, uint32_t world, uint32_t tiles_x,
-                                                        uint64_t tiles_per_rank, const uint8_t* __restrict__ slabs,
+                                                        uint64_t tiles_per_rank, uint32_t frames, const uint8_t* __restrict__ slabs,
                                                         uint8_t* __restrict__ rgb) {
-    const uint64_t npix = (uint64_t)w * h;
+    const uint64_t fpix = (uint64_t)w * h, npix = fpix * frames;
     for (uint64_t p = (uint64_t)blockIdx.x * RTX_BLOCK + threadIdx.x; p < npix; p += (uint64_t)gridDim.x * RTX_BLOCK) {
-        const uint32_t x = (uint32_t)(p % w), y = (uint32_t)(p / w);
+        const uint64_t frame = p / fpix, fp = p - frame * fpix;
+        const uint32_t x = (uint32_t)(fp % w), y = (uint32_t)(fp / w);
         const uint64_t tile = (uint64_t)(y / RTX_TILE) * tiles_x + x / RTX_TILE;
-        const uint64_t src = ((tile % world) * tiles_per_rank + tile / world) * 64 + (y % RTX_TILE) * 8 + x % RTX_TILE;
+        const uint64_t src = (((tile % world) * frames + frame) * tiles_per_rank + tile / world) * 64 + (y % RTX_TILE) * 8 + x % RTX_TILE;
         rgb[p * 3 + 0] = slabs[src * 3 + 0];
         rgb[p * 3 + 1] = slabs[src * 3 + 1];
         rgb[p * 3 + 2] = slabs[src * 3 + 2];
@@ -1198,8 +1220,11 @@ void rtx_clear_graphs(rtx_context* ctx) {
 }
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
-                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct, int async_slot) {
+                    uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct, int async_slot,
+                    uint32_t n_frames, const rtx_camera* cameras) {
     const DevScene& s = ctx->ds;
+    if (n_frames == 0 || n_frames > RTX_MAX_BATCH_FRAMES)
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a batch holds 1 to RTX_MAX_BATCH_FRAMES frames");
     rtx_context::AsyncSlot* slot = (async_slot >= 0) ? &ctx->async_slots[async_slot] : nullptr;
     hipStream_t st = ctx->stream;
     if (depth > RTX_MAX_DEPTH) {
@@ -1219,7 +1244,10 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     if (n_tiles >= (1ull << 25)) return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "image too large");
     const uint64_t tiles_per_rank = rtx_tiles_per_rank(w, h, world);
     const uint64_t tiles_local = (rank < n_tiles) ? (n_tiles - rank + world - 1) / world : 0;
-    const uint64_t rays_local = tiles_local * 64;
+    // A batch of several frames gives every frame the same number of ray slots on every rank (tiles_per_rank * 64;
+    // slots past a rank's own tiles hold invalid rays), so that a ray's index is also its place in the frames' slabs.
+    const uint64_t rays_per_frame = (n_frames > 1) ? tiles_per_rank * 64 : tiles_local * 64;
+    const uint64_t rays_local = rays_per_frame * n_frames;
     uint64_t primary = 0;   // pixels of this rank's tiles that lie inside the image
     {
         const uint32_t edge_w = w - (tiles_x - 1) * RTX_TILE, edge_h = h - (tiles_y - 1) * RTX_TILE;
@@ -1228,6 +1256,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             const uint32_t th = (tile / tiles_x == tiles_y - 1) ? edge_h : RTX_TILE;
             primary += (uint64_t)tw * th;
         }
+        primary *= n_frames;
     }
     // direct: d_rgb_tiles is a row-major [h][w][3] image (single GPU only); otherwise the rank's tile slab
     if (direct && world != 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "row-major output needs world == 1");
@@ -1236,12 +1265,13 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     // Row-major frames are painted completely by the kernels (k_shade_a paints the misses);
     // tile slabs have padding that no ray covers, and a depth-0 frame shades nothing.
     const bool clear_first = !direct || levels == 0;
-    const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x};
+    const OutMap out_map{d_rgb_tiles, direct ? w : 0u, tiles_x, n_frames, (uint32_t)rays_per_frame, w * h};
     if (!ctx->pinned) {
         void* p = nullptr;
-        RTX_HIP(ctx, hipHostMalloc(&p, 4 * 4096, hipHostMallocDefault));
+        RTX_HIP(ctx, hipHostMalloc(&p, 8 * 4096, hipHostMallocDefault));   // [0] counters, [1] next-level count, [2..3] counters of the frames in flight, [4..6] cameras of a batch
         ctx->pinned = p;
     }
+    static_assert(sizeof(CamSetup) * RTX_MAX_BATCH_FRAMES <= 4096, "a batch's cameras must fit one pinned page");
     Ctl* host_ctl = (Ctl*)((char*)ctx->pinned + (slot ? (size_t)(2 + async_slot) * 4096 : 0));
     uint32_t* host_next = (uint32_t*)((char*)ctx->pinned + 4096);
     static_assert(sizeof(Ctl) <= 4096, "Ctl must fit the pinned staging area");
@@ -1257,7 +1287,23 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     wk.n_samples = n_samples;
     wk.area_off = (s.n_area_lights && samples == 0) ? 1u : 0u;
 
-    const CamSetup cam = make_cam(ctx->camera, w, h);
+    const CamSetup cam = make_cam(cameras ? cameras[0] : ctx->camera, w, h);
+    const CamSetup* d_cams = nullptr;
+    uint64_t cam_hash = 0;   // recorded launch sequences hold the cameras they were recorded with
+    if (n_frames > 1) {
+        if (rays_local > batch || rays_local >= (1ull << 32))
+            return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "the frames of a batch must fit one ray batch (fewer frames, or a larger batch_pixels)");
+        if (!ctx->cam_dev) RTX_HIP(ctx, hipMalloc(&ctx->cam_dev, 3 * 4096));
+        const int page = slot ? 1 + async_slot : 0;
+        CamSetup* host_cams = (CamSetup*)((char*)ctx->pinned + (size_t)(4 + page) * 4096);
+        for (uint32_t f = 0; f < n_frames; ++f) host_cams[f] = make_cam(cameras ? cameras[f] : ctx->camera, w, h);
+        d_cams = (const CamSetup*)((char*)ctx->cam_dev + (size_t)page * 4096);
+        cam_hash = 1469598103934665603ull;
+        for (size_t k = 0; k < sizeof(CamSetup) * n_frames; ++k) cam_hash = (cam_hash ^ ((const uint8_t*)host_cams)[k]) * 1099511628211ull;
+    } else if (cameras) {
+        cam_hash = 1469598103934665603ull;
+        for (size_t k = 0; k < sizeof(CamSetup); ++k) cam_hash = (cam_hash ^ ((const uint8_t*)&cam)[k]) * 1099511628211ull;
+    }
     const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
     const bool any_shadow = !s.has_transparent;
     EventPool ev{slot ? &slot->events : &ctx->events};
@@ -1293,7 +1339,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                                  (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
                                  ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu) << 32) |
                                      trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu),
-                                 (uint64_t)(uintptr_t)wk.ctl, (uint64_t)ctx->graph_epoch};
+                                 (uint64_t)(uintptr_t)wk.ctl ^ (cam_hash * 0x9e3779b97f4a7c15ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;
         if (fg) {
@@ -1319,7 +1365,11 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     const bool recording = capture.active;
     if (!recording) RTX_HIP(ctx, hipEventRecord(f0, st));
     if (clear_first)
-        RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3, st));
+        RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, (direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3) * n_frames, st));
+    if (d_cams) {
+        const int page = slot ? 1 + async_slot : 0;
+        RTX_HIP(ctx, hipMemcpyAsync((void*)d_cams, (char*)ctx->pinned + (size_t)(4 + page) * 4096, sizeof(CamSetup) * n_frames, hipMemcpyHostToDevice, st));
+    }
     uint32_t n_batches = 0;
     uint64_t cur_batch = batch;
     int rollback = 0;
@@ -1328,7 +1378,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         ++n_batches;
         hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback, n_batches == 1 ? 1 : 0);
         rollback = 0;
-        const PrimaryGen gen{cam, first, rank, world, tiles_x, (uint32_t)n_tiles, 1u};   // level 0: rays come from their index
+        const PrimaryGen gen{cam, first, rank, world, tiles_x, (uint32_t)n_tiles, 1u, n_frames, (uint32_t)rays_per_frame, d_cams};   // level 0: rays come from their index
         PrimaryGen no_gen = gen;
         no_gen.enabled = 0;
         int qi = 0;
@@ -1347,7 +1397,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, a, b);
             closest_events.emplace_back(a, b);
             hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
-                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w}, pg, out_map, uo0);
+                               PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w, n_frames, (uint32_t)rays_per_frame}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = no_kt ? nullptr : ev.next(), d = no_kt ? nullptr : ev.next();
                 if (!no_kt && (!c || !d)) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -1392,7 +1442,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 (void)hipGetLastError();
                 if (fresh.exec) (void)hipGraphExecDestroy(fresh.exec);
                 ctx->opt_graphs = 0;
-                return rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, stats, direct, async_slot);
+                return rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, stats, direct, async_slot, n_frames, cameras);
             }
             fresh.has_shadow = !shadow_events.empty();
             if (ctx->graphs.size() >= 32) rtx_clear_graphs(ctx);   // a caller cycling through many buffers: start over
@@ -1420,6 +1470,8 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             // smaller batches (the workspace keeps its size, so relative capacity doubles).
             if (cur_batch <= 64)
                 return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "ray queues overflow even for one tile; raise the pool_factor option");
+            if (n_frames > 1)
+                return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "the ray queues overflowed for a batch of several frames: render fewer frames per batch or raise the pool_factor option");
             cur_batch = std::max<uint64_t>(64, (cur_batch / 2 + 63) & ~63ull);
             rollback = 1;   // k_batch_init restores the ray counters of the abandoned attempt
             continue;
@@ -1439,7 +1491,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
 
 // Enqueues a frame; at most two frames may be waiting to be collected.
 int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
-                          uint32_t world, uint8_t* d_rgb_tiles, bool direct) {
+                          uint32_t world, uint8_t* d_rgb_tiles, bool direct, uint32_t n_frames, const rtx_camera* cameras) {
     if (ctx->async_count >= 2) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "two frames are already in flight: collect one with rtx_render_wait");
     const int idx = (int)((ctx->async_head + ctx->async_count) & 1u);
     rtx_context::AsyncSlot& slot = ctx->async_slots[idx];
@@ -1448,7 +1500,9 @@ int rtx_render_async_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t dep
     slot.w = w; slot.h = h; slot.depth = depth; slot.samples = samples; slot.rank = rank; slot.world = world;
     slot.out = d_rgb_tiles;
     slot.direct = direct;
-    const int rc = rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, &slot.stats, direct, idx);
+    slot.n_frames = n_frames;
+    slot.cameras.assign(cameras ? cameras : nullptr, cameras ? cameras + n_frames : nullptr);
+    const int rc = rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles, &slot.stats, direct, idx, n_frames, cameras);
     if (rc != RTX_OK) {
         slot.used = false;
         return rc;
@@ -1475,7 +1529,8 @@ int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats) {
         }
         const Ctl* hc = (const Ctl*)((char*)ctx->pinned + (size_t)(2 + idx) * 4096);
         if (hc->overflow)   // rare: the frame's ray tree outgrew the queues; render it again the patient way
-            return rtx_render_impl(ctx, slot.w, slot.h, slot.depth, slot.samples, slot.rank, slot.world, slot.out, stats, slot.direct);
+            return rtx_render_impl(ctx, slot.w, slot.h, slot.depth, slot.samples, slot.rank, slot.world, slot.out, stats, slot.direct, -1,
+                                   slot.n_frames, slot.cameras.empty() ? nullptr : slot.cameras.data());
         note_hit_fraction(ctx, *hc, slot.primary);
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ce{{slot.a, slot.b}}, se;
         if (slot.has_shadow) se.emplace_back(slot.c, slot.d);
@@ -1512,10 +1567,10 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
     return RTX_OK;
 }
 
-int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb) {
+int rtx_assemble_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t world, const uint8_t* d_slabs, uint8_t* d_rgb, uint32_t n_frames) {
     const uint32_t tiles_x = (w + RTX_TILE - 1) / RTX_TILE;
-    hipLaunchKernelGGL(k_assemble, dim3(blocks_for((uint64_t)w * h, 8192)), dim3(RTX_BLOCK), 0, ctx->stream, w, h, world, tiles_x,
-                       rtx_tiles_per_rank(w, h, world), d_slabs, d_rgb);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks_for((uint64_t)w * h * n_frames, 8192)), dim3(RTX_BLOCK), 0, ctx->stream, w, h, world, tiles_x,
+                       rtx_tiles_per_rank(w, h, world), n_frames, d_slabs, d_rgb);
     RTX_HIP(ctx, hipGetLastError());
     return RTX_OK;
 }

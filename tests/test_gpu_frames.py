@@ -1,0 +1,146 @@
+"""Batches of frames (rtx_render_frames / rtx_render_frames_async / rtx_assemble_frames_async): several frames of one
+scene, one camera each, rendered as one set of launches. Every frame of a batch must be exactly the frame that a
+separate render with that camera gives (RayTracer::setup_camera + trace_rays per frame, src/lib.rs:69-84,257-277),
+whether the output is row-major images or tile slabs, and whatever the batch shares between frames."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _cameras(rtx, flat, n):
+    cams = []
+    for k in range(n):
+        c = rtx.Camera()
+        for name in ("pos", "view_dir", "ortho_up"):
+            for a in range(3):
+                getattr(c, name)[a] = getattr(flat.camera, name)[a]
+        c.focal_dist = flat.camera.focal_dist
+        c.vertical_fov = flat.camera.vertical_fov
+        c.pos[0] += 0.07 * k          # a short camera path
+        c.pos[1] += 0.03 * k
+        c.vertical_fov *= 1.0 + 0.05 * k
+        cams.append(c)
+    return cams
+
+
+def _single_frames(rtx, torch, flat, cams, w, h, depth, samples, force_mode):
+    """Each camera on its own: the scene is set again with that camera, as the reference would parse a new file."""
+    out, stats = [], []
+    for c in cams:
+        f = copy.copy(flat)
+        f.camera = c
+        with rtx.Context(0) as ctx:
+            ctx.set_option("force_mode", force_mode)
+            ctx.set_scene(f)
+            ctx.build()
+            img = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+            stats.append(ctx.render_device(w, h, depth, samples, img.data_ptr()))
+            torch.cuda.synchronize()
+            out.append(img.cpu().numpy().reshape(h, w, 3))
+    return out, stats
+
+
+@pytest.mark.parametrize("name,depth,samples", [("test05", 6, 1), ("test08", 10, 1), ("area", 4, 5)])
+def test_batch_equals_single_frames(rtx, name, depth, samples):
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path(name))
+    w, h, n = 90, 70, 3                      # not multiples of the tile size: edge tiles in every frame
+    cams = _cameras(rtx, flat, n)
+    single, st_single = _single_frames(rtx, torch, flat, cams, w, h, depth, samples, 2 if flat.n_prims > 4 else 0)
+    with rtx.Context(0) as ctx:
+        ctx.set_option("force_mode", 2 if flat.n_prims > 4 else 0)
+        ctx.set_scene(flat)
+        ctx.build()
+        batch = torch.full((n * h * w * 3,), 7, dtype=torch.uint8, device="cuda:0")
+        st = ctx.render_frames(n, cams, w, h, depth, samples, 0, 1, batch.data_ptr(), True)
+        torch.cuda.synchronize()
+        got = batch.cpu().numpy().reshape(n, h, w, 3)
+        for k in range(n):
+            assert np.array_equal(got[k], single[k]), "frame %d of the batch" % k
+        assert st.primary_rays == n * w * h
+        for field in ("shadow_rays", "reflect_rays", "refract_rays", "skipped_rays", "shaded_nodes"):
+            assert getattr(st, field) == sum(getattr(s, field) for s in st_single), field
+        # the same batch as tile slabs of two ranks, gathered and assembled
+        world = 2
+        tpr = rtx.tiles_per_rank(w, h, world)
+        slabs = torch.full((world, n, tpr * 192), 9, dtype=torch.uint8, device="cuda:0")
+        for r in range(world):
+            ctx.render_frames(n, cams, w, h, depth, samples, r, world, slabs[r].data_ptr(), False)
+        images = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.assemble_frames_async(n, w, h, world, slabs.data_ptr(), images.data_ptr())
+        torch.cuda.ExternalStream(ctx.stream()).synchronize()
+        assert torch.equal(images, batch)
+        # one frame with an explicit camera, and the scene's own camera for every frame
+        one = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_frames(1, [cams[2]], w, h, depth, samples, 0, 1, one.data_ptr(), True)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy().reshape(h, w, 3), single[2])
+        same = torch.zeros(2 * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_frames(2, None, w, h, depth, samples, 0, 1, same.data_ptr(), True)
+        torch.cuda.synchronize()
+        s2 = same.cpu().numpy().reshape(2, h, w, 3)
+        assert np.array_equal(s2[0], single[0]) and np.array_equal(s2[1], single[0])
+
+
+def test_batches_in_flight_and_recorded_launches(rtx):
+    """Two batches in flight through the async entry point, with launch recording on (kernel timing off): replayed
+    batches give the same images, and a batch with other cameras is not served by a recording made for the first."""
+    torch = pytest.importorskip("torch")
+    synth = importlib.import_module("rust-raytracer_amd.synth")
+    flat = synth.heightfield_scene(96)
+    w, h, n = 160, 120, 4
+    cams_a, cams_b = _cameras(rtx, flat, n), list(reversed(_cameras(rtx, flat, n)))
+    with rtx.Context(0) as ctx:
+        ctx.set_option("kernel_timing", 0)
+        ctx.set_scene(flat)
+        ctx.build()
+        ref_a = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ref_b = torch.zeros_like(ref_a)
+        ctx.render_frames(n, cams_a, w, h, 10, 1, 0, 1, ref_a.data_ptr(), True)
+        ctx.render_frames(n, cams_b, w, h, 10, 1, 0, 1, ref_b.data_ptr(), True)
+        torch.cuda.synchronize()
+        assert not torch.equal(ref_a, ref_b)
+        assert torch.equal(ref_a.view(n, -1)[0], ref_b.view(n, -1)[n - 1])
+        bufs = [torch.zeros_like(ref_a) for _ in range(2)]
+        seq = [cams_a, cams_a, cams_b, cams_a, cams_b, cams_b]
+        want = [ref_a, ref_a, ref_b, ref_a, ref_b, ref_b]
+        pending = []
+        for k, cams in enumerate(seq):
+            if len(pending) == 2:
+                j = pending.pop(0)
+                st = ctx.render_wait()
+                assert st.primary_rays == n * w * h
+                torch.cuda.synchronize()
+                assert torch.equal(bufs[j % 2], want[j]), "batch %d" % j
+            ctx.render_frames_async(n, cams, w, h, 10, 1, 0, 1, bufs[k % 2].data_ptr(), True)
+            pending.append(k)
+        while pending:
+            j = pending.pop(0)
+            ctx.render_wait()
+            torch.cuda.synchronize()
+            assert torch.equal(bufs[j % 2], want[j]), "batch %d" % j
+
+
+def test_batch_limits(rtx, gpu_ctx_factory):
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test04"))
+    ctx = gpu_ctx_factory(flat)
+    buf = torch.zeros(33 * 64 * 64 * 3, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(rtx.RtxError) as e:
+        ctx.render_frames(33, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)     # more than RTX_MAX_BATCH_FRAMES
+    assert e.value.status == 1
+    with pytest.raises(rtx.RtxError) as e:
+        ctx.render_frames(2, None, 64, 64, 5, 1, 0, 2, buf.data_ptr(), True)      # row-major output with two ranks
+    assert e.value.status == 1
+    ctx.set_option("batch_pixels", 4096)
+    with pytest.raises(rtx.RtxError) as e:
+        ctx.render_frames(2, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)      # 8192 rays do not fit one batch
+    assert e.value.status == 1 and "batch" in str(e.value)
+    ctx.render_frames(1, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)          # a single frame may still be cut into batches
