@@ -384,14 +384,15 @@ static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_sh
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
 template <bool SPH>
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
-    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
+    constexpr uint32_t kTop = top_nodes(closest_waves(SPH));
+    __shared__ uint4 top_lds[kTop * 4];
     TravStack st;
     st.set(lds, s);
     TopCache tc;
-    tc.load(top_lds, s);
+    tc.load(top_lds, s, kTop);
     if (ctl->overflow) return;   // the batch is being abandoned
     const uint32_t n = ctl->n_rays[qi];
     WaveStamp ws;
@@ -494,12 +495,14 @@ RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as
 // the chunk slots follow the ray order, so the node order is the ray order: no atomics, and
 // the same frame gives the same order every time.
 
-// Exclusive prefix of the per-chunk hit counts (one workgroup; at most a few thousand chunks);
+// Exclusive prefix of the per-chunk hit counts (one workgroup of 1024 threads: a batch of 16 Mi rays has 16 Ki chunks,
+// and a thread's chunks are read one dependent access after the other, so the kernel is as long as its longest thread);
 // sets the level's node count and clears the counts for the next launch.
-__global__ __launch_bounds__(RTX_BLOCK) void k_scan_chunks(Ctl* ctl, int qi, uint32_t* __restrict__ cnt, uint32_t* __restrict__ base) {
-    __shared__ uint32_t wave_sum[RTX_BLOCK / 64];
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_scan_chunks(Ctl* ctl, int qi, uint32_t* __restrict__ cnt, uint32_t* __restrict__ base) {
+    __shared__ uint32_t wave_sum[kScanThreads / 64];
     const uint32_t n_chunks = (ctl->n_rays[qi] + RTX_BLOCK * kShadeItems - 1) / (RTX_BLOCK * kShadeItems);
-    const uint32_t per = (n_chunks + RTX_BLOCK - 1) / RTX_BLOCK;
+    const uint32_t per = (n_chunks + kScanThreads - 1) / kScanThreads;
     const uint32_t t = threadIdx.x, lo = min(t * per, n_chunks), hi = min(lo + per, n_chunks);
     uint32_t sum = 0;
     for (uint32_t c = lo; c < hi; ++c) sum += cnt[c];
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_scan_chunks(Ctl* ctl, int qi, uin
         run += cnt[c];
         cnt[c] = 0;
     }
-    if (t == RTX_BLOCK - 1) ctl->n_nodes = run;
+    if (t == kScanThreads - 1) ctl->n_nodes = run;
 }
 // Level 0 with row-major output also paints the pixels of primary rays that missed
 // (bmp::Image::new's black), so the image needs no clearing pass.
@@ -740,14 +743,15 @@ struct ShadowTask {
 };
 
 template <bool ANY, bool AREA, bool SPH>
-__global__ __launch_bounds__(RTX_BLOCK) RTX_TRAV_OCCUPANCY void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(shadow_waves(ANY, AREA, SPH)) void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
-    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
+    constexpr uint32_t kTop = top_nodes(shadow_waves(ANY, AREA, SPH));
+    __shared__ uint4 top_lds[kTop * 4];
     TravStack st;
     st.set(lds, s);
     TopCache tc;
-    tc.load(top_lds, s);
+    tc.load(top_lds, s, kTop);
     Ctl* ctl = wk.ctl;
     if (ctl->overflow) return;
     ShadowTask<AREA> task;
@@ -1132,8 +1136,9 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
 // workgroups) and sized so that a wavefront expects `quarter_units / 4` work units: a launch with
 // few units runs faster on fewer wavefronts (every step of a ray waits less for the CU's address
 // unit and caches, and the expensive-first unit order needs more than one unit per wavefront).
-uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units) {
-    const uint32_t max_per_cu = (uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8);
+uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units, int resident) {
+    // `resident`: workgroups per CU the kernel is compiled for (closest_waves / shadow_waves)
+    const uint32_t max_per_cu = std::min<uint32_t>((uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8), (uint32_t)resident);
     const double waves = expected_items / 64.0 * 4.0 / (double)std::max<uint32_t>(quarter_units, 1);
     const double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
     const uint32_t wgs_per_cu = (uint32_t)std::min<double>(std::max<double>(per_cu, 1.0), (double)max_per_cu);
@@ -1145,7 +1150,7 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
 // launch, because events recorded between launches each cost the stream several idle microseconds.
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu)), block(RTX_BLOCK);
+    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(ctx->ds.n_spheres != 0))), block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
     if (ctx->ds.n_spheres) {
         if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
@@ -1154,7 +1159,7 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
         if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
         else hipLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
     }
-    if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(RTX_BLOCK), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
+    if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kScanThreads), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
 template <bool ANY, bool AREA>
 void launch_shadow_kernel(dim3 grid, hipStream_t st, hipEvent_t t0, hipEvent_t t1, const DevScene& s, const Work& wk, uint32_t depth,
@@ -1172,7 +1177,8 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
     const DevScene& s = ctx->ds;
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
-    const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu));
+    const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
+                                shadow_waves(any, area, s.n_spheres != 0)));
     if (any && area) launch_shadow_kernel<true, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (any) launch_shadow_kernel<true, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (area) launch_shadow_kernel<false, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
@@ -1337,8 +1343,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         if (s.n_lights > 0) (void)unit_order(ctx, 1, 0, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup);
         const uint64_t key[8] = {((uint64_t)w << 32) | h, ((uint64_t)depth << 32) | samples, ((uint64_t)rank << 32) | world,
                                  (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
-                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu) << 32) |
-                                     trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu),
+                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(s.n_spheres != 0)) << 32) |
+                                     trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
+                                                 shadow_waves(any_shadow, s.n_area_lights != 0, s.n_spheres != 0)),
                                  (uint64_t)(uintptr_t)wk.ctl ^ (cam_hash * 0x9e3779b97f4a7c15ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;

@@ -26,11 +26,12 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n,
                                                          float* __restrict__ tout, int exhaustive) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
-    __shared__ uint4 top_lds[RTX_TOP_NODES * 4];
+    constexpr uint32_t kTop = top_nodes(4);   // this kernel takes the compiler's register budget: four workgroups fit in any case
+    __shared__ uint4 top_lds[kTop * 4];
     TravStack st;
     st.set(lds, s);
     TopCache tc;
-    tc.load(top_lds, s);
+    tc.load(top_lds, s, kTop);
     // block-uniform trip count: the BVH query is cooperative inside a wavefront
     for (uint64_t base = (uint64_t)blockIdx.x * RTX_BLOCK; base < n; base += (uint64_t)gridDim.x * RTX_BLOCK) {
         const uint64_t i = base + threadIdx.x;

@@ -18,13 +18,18 @@
 #include "rtx_internal.h"
 
 #define RTX_BLOCK 256
-// Register budget of the traversal kernels, as waves per SIMD the compiler must make room for
-// (empty: the compiler's own choice).
-#ifndef RTX_TRAV_WAVES
-#define RTX_TRAV_OCCUPANCY
-#else
-#define RTX_TRAV_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RTX_TRAV_WAVES, RTX_TRAV_WAVES)))
-#endif
+// Workgroups of 256 threads (= waves per SIMD) that a traversal kernel keeps resident on a CU. The traversal loop is
+// a chain of dependent steps per ray, so a further resident workgroup is worth more than what it costs in registers
+// or LDS -- as long as nothing spills to scratch in the loop (measured per kernel: the figures below; one step up
+// spills 28-120 bytes per lane and is slower, except where noted). The kernels are compiled for exactly this many
+// waves, their LDS (stacks 16 KiB + shared slots 3 KiB + the copy of the tree's top levels) is sized to fit it, and
+// launches ask for no more workgroups per CU than that (more would queue behind the others and end the launch late).
+//   closest hit:           triangle-only 74 registers -> 6; with spheres 103 -> 5 (28 bytes of scratch, still -1..-6 %)
+//   any-hit shadow rays:   triangle-only 79-82 -> 6; with spheres, point lights 109 -> 5 (config 5: -4 %), area lights 112 -> 4
+//   closest-hit shadow rays (transparent materials): triangle-only 89-95 -> 5; with spheres 118-124 -> 4
+constexpr int closest_waves(bool sph) { return sph ? 5 : 6; }
+constexpr int shadow_waves(bool any, bool area, bool sph) { return sph ? ((any && !area) ? 5 : 4) : (any ? 6 : 5); }
+#define RTX_WAVES_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 RTX_D uint32_t f2u(float f) { return __float_as_uint(f); }
 RTX_D float u2f(uint32_t u) { return __uint_as_float(u); }
@@ -316,22 +321,22 @@ constexpr int kRefDone = 0x7fffffff;   // "no more work" reference (never a node
 struct Fetched {
     uint4 a, b, c, d;
 };
-// The first RTX_TOP_NODES nodes of the tree -- its top levels: nodes are numbered in level order -- are copied into
+// The first top_nodes(waves) nodes of the tree -- its top levels: nodes are numbered in level order -- are copied into
 // LDS by every traversal workgroup. Every ray walks through them, and a wavefront's 64 divergent 64-byte fetches
 // occupy the CU's vector-memory path for ~125 cycles even when they all hit in L1 (four dwordx4 instructions, ~31
-// cycles each), which is what bounds these kernels; the same fetch from LDS is four ds_read_b128 (~16 cycles) with a
-// fraction of the latency. 320 nodes = 20 KiB: with the traversal stacks 39 KiB per workgroup, four workgroups per CU.
-#ifndef RTX_TOP_NODES
-#define RTX_TOP_NODES 320
-#endif
+// cycles each); the same fetch from LDS is four ds_read_b128 (~16 cycles) with a fraction of the latency.
+// How many: as many as the LDS left by the kernel's resident workgroups holds (160 KiB per CU; a workgroup's stacks
+// and shared slots take 19 KiB): 4 workgroups -> 320 nodes (20 KiB, levels 0-4 of a full tree), 5 -> 128, 6 -> 64
+// (levels 0-2 and most of level 3). The cache is worth 1-2 %, a resident workgroup 5-12 %.
+constexpr uint32_t top_nodes(int waves) { return waves <= 4 ? 320u : waves == 5 ? 128u : 64u; }
 typedef unsigned int rtx_u32x4 __attribute__((ext_vector_type(4)));
 struct TopCache {
     RTX_LDS_PTR(rtx_u32x4) base;
     uint32_t count;   // nodes cached (0: none, e.g. no tree)
-    // All threads of the workgroup call this before the first traversal step; `lds` holds RTX_TOP_NODES * 4 quads.
-    RTX_D void load(uint4* lds, const DevScene& s) {
+    // All threads of the workgroup call this before the first traversal step; `lds` holds `capacity` * 4 quads.
+    RTX_D void load(uint4* lds, const DevScene& s, uint32_t capacity) {
         base = (RTX_LDS_PTR(rtx_u32x4))lds;
-        count = s.uses_bvh ? min(s.n_nodes, (uint32_t)RTX_TOP_NODES) : 0u;
+        count = s.uses_bvh ? min(s.n_nodes, capacity) : 0u;
         const uint4* src = reinterpret_cast<const uint4*>(s.nodes);
         for (uint32_t k = threadIdx.x; k < count * 4u; k += RTX_BLOCK) lds[k] = src[k];
         __syncthreads();
