@@ -388,18 +388,29 @@ __device__ __forceinline__ uint32_t f16_bits_down(float r) {
 // cancellation error grows with the distance between ray origin and centre and is covered at traversal time from the
 // smallest sphere radius of each subtree, carried in the box minimum's w (+inf: no sphere) -- and walks towards the root.
 // At every inner node the first child to arrive stops; the second one finds its sibling's box complete, forms the
-// union (BoundingBox +, shapes/mod.rs:86-104) and goes on. The two arrivals may run on different CUs and XCDs, whose
-// L1s and L2s do not see each other's plain stores: the boxes are stored write-through (sc0 sc1), the storing wavefront
-// waits for its stores (vmcnt(0)) before it counts its arrival with a device-scope atomic, and the wavefront whose
-// arrival came second loads the sibling's box with loads that bypass the caches (sc0 sc1). No cache is flushed or
-// invalidated on the way (agent-scope fences per step cost this launch a factor of five).
+// union (BoundingBox +, shapes/mod.rs:86-104) and goes on.
+// A workgroup's 256 leaves are consecutive in Morton order, so nearly all inner nodes above them (about 250 of 255)
+// cover leaves of this workgroup only -- a node's index lies inside its own leaf range, so "first and last leaf belong
+// to this workgroup" identifies them and `index - first leaf of the workgroup` is a slot in LDS. For those nodes the
+// arrival counter and the children's boxes live in LDS (an LDS atomic and two LDS reads per step instead of two
+// dependent trips to memory); only the few nodes whose leaves span workgroups use the device-wide protocol:
+// the two arrivals may run on different CUs and XCDs, whose L1s and L2s do not see each other's plain stores, so the
+// arriving child's box is stored write-through (sc0 sc1), the storing wavefront waits for its stores (vmcnt(0)) before
+// it counts its arrival with a device-scope atomic, and the wavefront whose arrival came second loads the sibling's box
+// with loads that bypass the caches (sc0 sc1). No cache is flushed or invalidated on the way (agent-scope fences per
+// step cost this launch a factor of five). Every box also goes to box[] with a plain store for the launches that follow.
 // *root_height receives the height of the binary tree. rtx_set_option("verify_build") recomputes every box afterwards.
 __global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
                                                      const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                                                      BuildNode* __restrict__ bn, float4* __restrict__ box, PadParams pp, int leaf_max,
                                                      uint32_t* __restrict__ root_height) {
-    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    __shared__ uint32_t s_cnt[kThreads];        // arrivals at the inner nodes local to this workgroup
+    __shared__ float4 s_leaf[kThreads][2];      // boxes of this workgroup's leaves
+    __shared__ float4 s_inner[kThreads][2];     // boxes of its local inner nodes
+    const uint32_t bs = blockIdx.x * kThreads, be = min(bs + (uint32_t)kThreads, n);   // this workgroup's leaves
+    const uint32_t j = bs + threadIdx.x;
     const bool live = j < n;
+    s_cnt[threadIdx.x] = 0;
     int me = -1, cur = -1;
     float4 mn = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mx = mn;
     uint32_t h = 0;
@@ -417,30 +428,67 @@ __global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, cons
         me = (int)((n - 1) + j);
         mn = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
         mx = make_float4(b.x + pad, b.y + pad, b.z + pad, __uint_as_float(0u));
-        store_through(&box[2 * (size_t)me], mn);
-        store_through(&box[2 * (size_t)me + 1], mx);
+        box[2 * (size_t)me] = mn;
+        box[2 * (size_t)me + 1] = mx;
+        s_leaf[threadIdx.x][0] = mn;
+        s_leaf[threadIdx.x][1] = mx;
         cur = (n > 1) ? bn[me].parent : -1;
     }
+    __syncthreads();   // counters cleared, leaf boxes in place
     // bounded by the tree height; every lane leaves the loop (first arrival, or the root)
     while (__ballot(cur >= 0)) {
-        uint32_t old = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's boxes have reached memory before its arrivals count
-        if (cur >= 0) old = __hip_atomic_fetch_add(&bn[cur].counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool second = cur >= 0 && old == 1u;
+        int l = 0, r = 0, first = 0, last = 0, parent = -1;
+        if (cur >= 0) {   // written by the launch before this one
+            l = bn[cur].l; r = bn[cur].r; first = bn[cur].first; last = bn[cur].last; parent = bn[cur].parent;
+        }
+        const bool local = cur >= 0 && (uint32_t)first >= bs && (uint32_t)last < be;
+        const bool global = cur >= 0 && !local;
+        bool second = false;
+        float4 sa = mn, sb = mx;
+        const int sib = (l == me) ? r : l;
+        if (local) {
+            // this lane's box is in LDS already (written below, or above for a leaf); LDS serves one wavefront's accesses in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t old = __hip_atomic_fetch_add(&s_cnt[(uint32_t)cur - bs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            second = old == 1u;
+            if (second) {
+                if (sib >= (int)(n - 1)) {
+                    sa = s_leaf[(uint32_t)sib - (n - 1) - bs][0];
+                    sb = s_leaf[(uint32_t)sib - (n - 1) - bs][1];
+                } else {
+                    sa = s_inner[(uint32_t)sib - bs][0];
+                    sb = s_inner[(uint32_t)sib - bs][1];
+                }
+            }
+        }
+        if (__ballot(global)) {
+            if (global) {
+                store_through(&box[2 * (size_t)me], mn);
+                store_through(&box[2 * (size_t)me + 1], mx);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's boxes have reached memory before its arrivals count
+            if (global) {
+                const uint32_t old = __hip_atomic_fetch_add(&bn[cur].counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                second = old == 1u;
+                if (second) load_through2(&box[2 * (size_t)sib], sa, sb);
+            }
+        }
         if (!second) cur = -1;
         if (second) {
-            const int l = bn[cur].l, r = bn[cur].r;     // written by the launch before this one
-            const int sib = (l == me) ? r : l;
-            float4 sa, sb;
-            load_through2(&box[2 * (size_t)sib], sa, sb);
             mn = make_float4(fminf(mn.x, sa.x), fminf(mn.y, sa.y), fminf(mn.z, sa.z), fminf(mn.w, sa.w));
-            const int size = bn[cur].last - bn[cur].first + 1;
+            const int size = last - first + 1;
             h = (size <= leaf_max) ? 0u : min(1u + max(h, __float_as_uint(sb.w)), 255u);
             mx = make_float4(fmaxf(mx.x, sb.x), fmaxf(mx.y, sb.y), fmaxf(mx.z, sb.z), __uint_as_float(h));
-            store_through(&box[2 * (size_t)cur], mn);
-            store_through(&box[2 * (size_t)cur + 1], mx);
+            box[2 * (size_t)cur] = mn;
+            box[2 * (size_t)cur + 1] = mx;
+            if (local) {
+                s_inner[(uint32_t)cur - bs][0] = mn;
+                s_inner[(uint32_t)cur - bs][1] = mx;
+                bn[cur].counter = 2u;   // both arrivals were counted in LDS; the record says so like any other node's
+            }
             me = cur;
-            cur = bn[cur].parent;
+            cur = parent;
             if (cur < 0) *root_height = h;   // the root is complete
         }
     }
@@ -893,42 +941,49 @@ int rtx_bvh_build(rtx_context* ctx) {
             TRY_HIP(hipMemsetAsync(mismatches, 0, 4, st));
             hipLaunchKernelGGL(k_verify_refit, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (int)n, bn, box, leaf_max, mismatches);
         }
-        // The height bounds the number of emission launches; this is the build's only wait before its end.
-        uint32_t height = 0;
-        uint32_t bad_boxes = 0;
-        if (mismatches) TRY_HIP(hipMemcpyAsync(&bad_boxes, mismatches, 4, hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipMemcpyAsync(&height, root_height, 4, hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipStreamSynchronize(st));
-        if (bad_boxes) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "verify_build: " + std::to_string(bad_boxes) + " inner nodes whose box is not the union of their children's"); }
-        if (height == 0 || height >= 255) { cleanup(); return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows"); }
         // Emission: one launch per level of the 4-wide tree, from the root down, into a temporary array with one slot per
         // binary inner node (an upper bound); the nodes that exist are then copied to an allocation of their exact size.
+        // How many levels there are is not known here (at most the binary tree's height, usually about half of it), and
+        // asking the device would stall the stream in mid-build: a first round of launches covers trees of up to 2^36
+        // well-spread primitives, a launch for a level that does not exist ends at once, and the build's one wait -- after
+        // everything is enqueued -- tells whether a deeper tree needs further rounds.
         TRY(tmp.get(&nodes_tmp, n - 1));
+        std::vector<LevelInfo> hl(kMaxLevels + 2);
+        uint32_t height = 0, bad_boxes = 0, launched = 0;
         {
             const int root = 0;
             const LevelInfo first{1u, 0u};
             TRY_HIP(hipMemcpyAsync(queue[0], &root, 4, hipMemcpyHostToDevice, st));
             TRY_HIP(hipMemcpyAsync(&lvl[0], &first, sizeof(first), hipMemcpyHostToDevice, st));
-            // a level of the 4-wide tree has at most min(4^level, n / 2) nodes: small grids for the top levels
-            uint64_t width = 1;
-            for (uint32_t level = 0; level < height; ++level) {
+        }
+        uint64_t width = 1;   // a level of the 4-wide tree has at most min(4^level, n / 2) nodes: small grids for the top levels
+        bool recs_made = false;
+        for (uint32_t round_levels = 18;; round_levels = 8) {
+            for (uint32_t k = 0; k < round_levels && launched < kMaxLevels; ++k, ++launched) {
                 const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_for(std::min<uint64_t>(width, n)), 2048);
-                hipLaunchKernelGGL(k_emit4, dim3(grid), dim3(kThreads), 0, st, (int)n, level, queue[level & 1], queue[(level & 1) ^ 1], lvl, bn, box,
-                                   nodes_tmp, leaf_max);
+                hipLaunchKernelGGL(k_emit4, dim3(grid), dim3(kThreads), 0, st, (int)n, launched, queue[launched & 1], queue[(launched & 1) ^ 1], lvl, bn,
+                                   box, nodes_tmp, leaf_max);
                 width = std::min<uint64_t>(width * 4, n);
             }
+            if (!recs_made) {
+                hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
+                recs_made = true;
+            }
+            if (mismatches) TRY_HIP(hipMemcpyAsync(&bad_boxes, mismatches, 4, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipMemcpyAsync(&height, root_height, 4, hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipMemcpyAsync(hl.data(), lvl, hl.size() * sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
+            TRY_HIP(hipStreamSynchronize(st));
+            if (bad_boxes) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "verify_build: " + std::to_string(bad_boxes) + " inner nodes whose box is not the union of their children's"); }
+            if (height == 0 || height >= 255) { cleanup(); return rtx_fail(ctx, RTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack allows"); }
+            if (hl[launched].count == 0 || launched >= height) break;   // no roots were reserved for a further level
         }
-        hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
-        std::vector<LevelInfo> hl(kMaxLevels + 2);
-        TRY_HIP(hipMemcpyAsync(hl.data(), lvl, hl.size() * sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
-        TRY_HIP(hipStreamSynchronize(st));
         uint64_t n_nodes = 0, n_leaves = 0;
-        for (uint32_t level = 0; level < height && hl[level].count; ++level) {
+        for (uint32_t level = 0; level < launched && hl[level].count; ++level) {
             n_nodes += hl[level].count;
             n_leaves += hl[level].leaves;
             levels4 = level + 1;
         }
-        if (hl[height].count != 0 || n_nodes == 0 || n_nodes > (uint64_t)n - 1) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
+        if (hl[launched].count != 0 || n_nodes == 0 || n_nodes > (uint64_t)n - 1 || n_leaves == 0) { cleanup(); return rtx_fail(ctx, RTX_ERR_HIP, "BVH emission did not terminate"); }
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, store->ptrs, &nodes, (size_t)n_nodes));
         TRY_HIP(hipMemcpyAsync(nodes, nodes_tmp, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToDevice, st));
