@@ -128,6 +128,42 @@ def test_batches_in_flight_and_recorded_launches(rtx):
             assert torch.equal(bufs[j % 2], want[j]), "batch %d" % j
 
 
+@pytest.mark.parametrize("w,h,world", [(96, 52, 3), (64, 64, 2), (100, 52, 3)])
+def test_assembly_of_batches(rtx, w, h, world):
+    """Slabs of `world` ranks, gathered, against the row-major batch; neither width nor height need be a multiple of the
+    tile size."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test06"))
+    n = 3
+    cams = _cameras(rtx, flat, n)
+    with rtx.Context(0) as ctx:
+        ctx.set_scene(flat)
+        ctx.build()
+        want = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_frames(n, cams, w, h, 5, 1, 0, 1, want.data_ptr(), True)
+        tpr = rtx.tiles_per_rank(w, h, world)
+        slabs = torch.full((world, n, tpr * 192), 5, dtype=torch.uint8, device="cuda:0")
+        for r in range(world):
+            ctx.render_frames(n, cams, w, h, 5, 1, r, world, slabs[r].data_ptr(), False)
+        got = torch.full((n * h * w * 3,), 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.assemble_frames_async(n, w, h, world, slabs.data_ptr(), got.data_ptr())
+        torch.cuda.ExternalStream(ctx.stream()).synchronize()
+        assert want.max().item() > 0
+        assert torch.equal(got, want)
+        # one frame through the older entry point
+        one = torch.full((h * w * 3,), 3, dtype=torch.uint8, device="cuda:0")
+        single = torch.zeros((world, tpr * 192), dtype=torch.uint8, device="cuda:0")
+        for r in range(world):
+            ctx.render_tiles(w, h, 5, 1, r, world, single[r].data_ptr())
+        ctx.assemble_tiles(w, h, world, single.data_ptr(), one.data_ptr())
+        torch.cuda.synchronize()
+        whole = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_device(w, h, 5, 1, whole.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(one, whole)
+
+
 def test_batch_limits(rtx, gpu_ctx_factory):
     torch = pytest.importorskip("torch")
     flat = rtx.parse_scene(scene_path("test04"))
