@@ -347,8 +347,7 @@ def main():
         if not multi:
             return
         if abi:      # gather-to-root and assembly inside the library; rank 0 ends up with the image(s)
-            for f in range(fpb):
-                ctx.gather_frame(w, h, slabs[idx].data_ptr() + f * tpr * 192, image.data_ptr() + f * h * w * 3, 0)
+            ctx.gather_frames(fpb, w, h, slabs[idx].data_ptr(), image.data_ptr(), 0)
             return
         if gloo:
             dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())

@@ -317,6 +317,10 @@ int rtx_comm_destroy(rtx_context* ctx);
 int rtx_scene_broadcast(rtx_context* ctx, const rtx_scene_desc* scene, uint32_t root);
 int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles, uint8_t* d_rgb,
                      uint32_t root);
+/* The same for a batch (rtx_render_frames with slabs): d_rgb_tiles = this rank's [n_frames][tiles_per_rank][8*8*3],
+ * d_rgb on the root receives [n_frames][h][w][3]; one exchange for the whole batch. */
+int rtx_gather_frames(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles,
+                      uint8_t* d_rgb, uint32_t root);
 
 /* Diagnostics (no counterpart in the reference): with the "stamps" option set, every
  * wavefront of the last closest-hit launch (kind 0) or shadow launch (kind 1) has

@@ -158,6 +158,8 @@ extern "C" {
     pub fn rtx_scene_broadcast(ctx: *mut rtx_context, scene: *const rtx_scene_desc, root: u32) -> c_int;
     pub fn rtx_gather_frame(ctx: *mut rtx_context, width: u32, height: u32, d_rgb_tiles: *const u8, d_rgb: *mut u8,
                             root: u32) -> c_int;
+    pub fn rtx_gather_frames(ctx: *mut rtx_context, n_frames: u32, width: u32, height: u32, d_rgb_tiles: *const u8,
+                             d_rgb: *mut u8, root: u32) -> c_int;
     pub fn rtx_debug_stamps(ctx: *mut rtx_context, kind: c_int, out: *mut u64, capacity: u64) -> u64;
     pub fn rtx_stream(ctx: *mut rtx_context) -> *mut c_void;
 }

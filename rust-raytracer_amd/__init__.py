@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
     "rtx_intersect_batch_device_noalloc", "rtx_scene_set_device", "rtx_clone",
     "rtx_comm_unique_id", "rtx_comm_init", "rtx_comm_destroy", "rtx_scene_broadcast", "rtx_gather_frame",
-    "rtx_render_frames", "rtx_render_frames_async", "rtx_assemble_frames_async",
+    "rtx_render_frames", "rtx_render_frames_async", "rtx_assemble_frames_async", "rtx_gather_frames",
 ]
 MAX_BATCH_FRAMES = 32
 
@@ -165,6 +165,7 @@ def lib():
         L.rtx_comm_destroy.argtypes = [vp]
         L.rtx_scene_broadcast.argtypes = [vp, vp, u32]
         L.rtx_gather_frame.argtypes = [vp, u32, u32, vp, vp, u32]
+        L.rtx_gather_frames.argtypes = [vp, u32, u32, u32, vp, vp, u32]
         L.rtx_debug_stamps.argtypes = [vp, C.c_int, vp, u64]
         L.rtx_debug_stamps.restype = u64
         _lib = L
@@ -385,6 +386,10 @@ class Context:
     def gather_frame(self, width, height, d_rgb_tiles, d_rgb, root=0):
         """Collective: this rank's slab (device pointer) to the root, which assembles the image into d_rgb (device pointer)."""
         self._check(self._L.rtx_gather_frame(self._h, width, height, d_rgb_tiles, d_rgb, int(root)))
+
+    def gather_frames(self, n_frames, width, height, d_rgb_tiles, d_rgb, root=0):
+        """Collective: this rank's slabs of a batch to the root, which assembles the batch's images into d_rgb."""
+        self._check(self._L.rtx_gather_frames(self._h, n_frames, width, height, d_rgb_tiles, d_rgb, int(root)))
 
     def build(self):
         st = BuildStats()

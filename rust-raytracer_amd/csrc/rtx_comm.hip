@@ -216,10 +216,12 @@ int rtx_scene_broadcast(rtx_context* ctx, const rtx_scene_desc* scene, uint32_t 
     return rtx_scene_set_device(ctx, &d);   // copies device-to-device; the receive buffers are freed on return
 }
 
-int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles, uint8_t* d_rgb, uint32_t root) {
+int rtx_gather_frames(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles, uint8_t* d_rgb,
+                      uint32_t root) {
     if (!ctx) return RTX_ERR_INVALID_ARG;
     if (!ctx->comm) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "rtx_comm_init has not been called on this context");
-    if (width == 0 || height == 0 || !d_rgb_tiles || root >= ctx->comm_world) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "bad argument");
+    if (n_frames == 0 || n_frames > RTX_MAX_BATCH_FRAMES || width == 0 || height == 0 || !d_rgb_tiles || root >= ctx->comm_world)
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "bad argument");
     const bool is_root = ctx->comm_rank == root;
     if (is_root && !d_rgb) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "the root rank needs an image buffer");
     Rccl* R = rccl();
@@ -228,8 +230,8 @@ int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const ui
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     hipStream_t st = ctx->stream;
     const uint32_t world = ctx->comm_world;
-    const size_t slab = (size_t)rtx_tiles_per_rank(width, height, world) * 64 * 3;
-    if (is_root && ctx->gather_size < slab * world) {   // kept for the next frame
+    const size_t slab = (size_t)rtx_tiles_per_rank(width, height, world) * 64 * 3 * n_frames;   // a rank's slabs of the batch
+    if (is_root && ctx->gather_size < slab * world) {   // kept for the next batch
         RTX_HIP(ctx, hipStreamSynchronize(st));
         if (ctx->gather_buf) (void)hipFree(ctx->gather_buf);
         ctx->gather_buf = nullptr;
@@ -240,7 +242,7 @@ int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const ui
         ctx->gather_size = slab * world;
     }
     // A gather, not an all-gather: every slab crosses one link once, all into the root (7 links in parallel on an
-    // 8-GPU node); the root's own slab is a device copy.
+    // 8-GPU node); the root's own slabs are a device copy.
     RTX_NCCL(ctx, R, R->GroupStart());
     if (is_root) {
         for (uint32_t r = 0; r < world; ++r) {
@@ -253,11 +255,15 @@ int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const ui
     }
     RTX_NCCL(ctx, R, R->GroupEnd());
     if (is_root) {
-        const int rc = rtx_assemble_impl(ctx, width, height, world, (const uint8_t*)ctx->gather_buf, d_rgb);
+        const int rc = rtx_assemble_impl(ctx, width, height, world, (const uint8_t*)ctx->gather_buf, d_rgb, n_frames);
         if (rc != RTX_OK) return rc;
     }
     RTX_HIP(ctx, hipStreamSynchronize(st));
     return RTX_OK;
+}
+
+int rtx_gather_frame(rtx_context* ctx, uint32_t width, uint32_t height, const uint8_t* d_rgb_tiles, uint8_t* d_rgb, uint32_t root) {
+    return rtx_gather_frames(ctx, 1, width, height, d_rgb_tiles, d_rgb, root);
 }
 
 }  // extern "C"

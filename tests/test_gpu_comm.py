@@ -35,5 +35,14 @@ def test_one_rank_broadcast_and_gather_equal_the_plain_path(rtx, gpu_ctx_factory
         torch.cuda.synchronize()
         assert st.traced_rays == st_ref.traced_rays
         assert np.array_equal(img.cpu().numpy().reshape(h, w, 3), rgb_ref)
+        # a batch of three frames through the batch form of the gather (the scene's camera for all: three equal images)
+        slabs = torch.zeros(3 * tpr * 192, dtype=torch.uint8, device="cuda:0")
+        imgs = torch.zeros(3 * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.render_frames(3, None, w, h, 10, 10, 0, 1, slabs.data_ptr(), False)
+        ctx.gather_frames(3, w, h, slabs.data_ptr(), imgs.data_ptr(), 0)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert np.array_equal(imgs.cpu().numpy().reshape(3, h, w, 3)[k], rgb_ref)
         ctx.comm_destroy()
         ctx.comm_destroy()                                # idempotent
