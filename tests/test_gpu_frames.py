@@ -164,6 +164,29 @@ def test_assembly_of_batches(rtx, w, h, world):
         assert torch.equal(one, whole)
 
 
+def test_largest_batch(rtx):
+    """RTX_MAX_BATCH_FRAMES frames with a camera each: every frame equals the frame of a batch of one."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test03"))
+    n, w, h = rtx.MAX_BATCH_FRAMES, 48, 40
+    cams = _cameras(rtx, flat, n)
+    with rtx.Context(0) as ctx:
+        ctx.set_scene(flat)
+        ctx.build()
+        batch = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        st = ctx.render_frames(n, cams, w, h, 5, 1, 0, 1, batch.data_ptr(), True)
+        assert st.primary_rays == n * w * h
+        one = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        distinct = set()
+        for k in (0, 1, n // 2, n - 1):
+            ctx.render_frames(1, [cams[k]], w, h, 5, 1, 0, 1, one.data_ptr(), True)
+            torch.cuda.synchronize()
+            assert torch.equal(batch[k * h * w * 3:(k + 1) * h * w * 3], one), "frame %d" % k
+            distinct.add(bytes(one.cpu().numpy().tobytes()))
+        assert len(distinct) > 1
+
+
 def test_batch_limits(rtx, gpu_ctx_factory):
     torch = pytest.importorskip("torch")
     flat = rtx.parse_scene(scene_path("test04"))
