@@ -284,6 +284,7 @@ def main():
     slabs = [torch.zeros(fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
     gathered = [torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
     gathered_host = torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
+    torch.cuda.synchronize()      # torch clears these on its own stream; the library's streams do not wait for it
     image = images[0]
     acc = {}
     gather_wait = [0.0]   # seconds the host waited for slabs that had not arrived when they were needed
@@ -425,6 +426,7 @@ def main():
     sharded_equal = None
     if multi and rank == 0:   # outside the timed region: the assembled frame against a single-GPU frame
         whole = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()      # torch fills the buffer on ITS stream; the library renders on its own
         ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
         torch.cuda.synchronize()
         sharded_equal = all(bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3])) for f in range(fpb))
@@ -572,6 +574,7 @@ def main():
                 ctx.set_option("kernel_timing", 0)
                 trio = [ctx] + extra
                 bufs = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(6)]
+                torch.cuda.synchronize()
 
                 def run1(n):      # frame by frame on one context, two frames in flight: the configuration of earlier rounds
                     ms = [0.0, 0.0, 0]
@@ -620,6 +623,7 @@ def main():
             try:
                 w4, h4 = 3840, 2160
                 bufs4 = [torch.zeros(h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+                torch.cuda.synchronize()
                 ctx.set_option("kernel_timing", 0)
 
                 def run4(n):
