@@ -187,6 +187,30 @@ def test_largest_batch(rtx):
         assert len(distinct) > 1
 
 
+def test_batch_whose_ray_tree_outgrows_the_queues(rtx):
+    """A batch cannot be cut into smaller ray batches the way a single frame can: an overflow of the ray queues is
+    reported, through the synchronous and the asynchronous entry point, and the context goes on working."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test05"))          # glass: every hit spawns two rays
+    w, h, n = 64, 64, 2
+    with rtx.Context(0) as ctx:
+        ctx.set_option("pool_factor", 1)
+        ctx.set_scene(flat)
+        ctx.build()
+        buf = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        single, _ = ctx.render(w, h, 10, 1)                # one frame: re-rendered in smaller batches if need be
+        try:
+            ctx.render_frames(n, None, w, h, 10, 1, 0, 1, buf.data_ptr(), True)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().reshape(n, h, w, 3)
+            assert np.array_equal(got[0], single) and np.array_equal(got[1], single)     # it fitted after all
+        except rtx.RtxError as e:
+            assert e.status == 7 and "batch" in str(e)
+        again, _ = ctx.render(w, h, 10, 1)
+        assert np.array_equal(again, single)
+
+
 def test_batch_limits(rtx, gpu_ctx_factory):
     torch = pytest.importorskip("torch")
     flat = rtx.parse_scene(scene_path("test04"))
