@@ -220,7 +220,8 @@ constexpr uint32_t kGroupLog2 = RTX_GROUP_LOG2, kGroup = 1u << kGroupLog2;
 struct UnitOrder {
     uint32_t n_cost;    // unit count of the launch that last added to cost[] (0: none, or too many for cap)
     uint32_t n_order;   // unit count whose groups order[] is a permutation of (0: none)
-    uint32_t cap, pad;  // capacity in groups
+    uint32_t cap;       // capacity in groups
+    uint32_t fine_units; // per shard: the first fine_units units go out one per atomic, the cheap rest eight per atomic
     RTX_D uint32_t* cost() { return reinterpret_cast<uint32_t*>(this + 1); }          // [cap] summed durations, 10 ns ticks
     RTX_D uint32_t* order() { return reinterpret_cast<uint32_t*>(this + 1) + cap; }   // [cap] groups, most expensive first
 };
@@ -228,6 +229,7 @@ struct UnitOrder {
 struct UnitQueue {
     uint32_t* heads;        // [8][32]
     uint32_t n_units, n_groups, per_shard, shard, probe;
+    uint32_t res_k = 0, res_n = 0, fine = 0xffffffffu;   // COARSE: next position of the current shard's counter that this wavefront holds, how many it holds
     const uint32_t* order;  // sorted position -> group, or nullptr
     UnitOrder* uo;
     RTX_D void init(uint32_t* h, uint64_t n_items, UnitOrder* uo_) {
@@ -239,6 +241,7 @@ struct UnitQueue {
         probe = 0;
         uo = uo_;
         order = (uo && n_units > 0 && uo->n_order == n_units) ? uo->order() : nullptr;
+        fine = order ? uo->fine_units : 0xffffffffu;
     }
     // Called once per launch by every wavefront after init (only one thread writes).
     RTX_D void announce() {
@@ -249,20 +252,37 @@ struct UnitQueue {
             atomicMax(&uo->cost()[unit >> kGroupLog2], (uint32_t)(wall_clock64() - t0));   // a group is as urgent as its slowest unit: its units go out together
     }
     // Wave-uniform: next unit for this wavefront, or 0xffffffff when every shard is empty.
+    // COARSE: units past the expensive ones of a shard (their groups cost under 1/16 of the dearest group: rays that
+    // leave the scene at once) are reserved eight per atomic, so that the end of a launch, when nothing else is left,
+    // is not one atomic round trip per unit and wavefront.
+    template <bool COARSE = false>
     RTX_D uint32_t next() {
         uint32_t unit = 0xffffffffu;
         if ((threadIdx.x & 63) == 0) {
             while (probe < 8) {
-                const uint32_t sh = (shard + probe) & 7u;
                 if (order) {   // shard sh owns the groups at sorted positions sh, sh + 8, ...: every shard starts with expensive ones
-                    const uint32_t k = atomicAdd(&heads[sh * 32], 1u);
+                    const uint32_t sh = (shard + probe) & 7u;
+                    uint32_t k;
+                    if (COARSE && res_n) {
+                        k = res_k++;
+                        --res_n;
+                    } else {
+                        const uint32_t take = (COARSE && res_k > fine) ? 8u : 1u;   // res_k: one past the last position seen on this shard
+                        k = atomicAdd(&heads[sh * 32], take);
+                        if (COARSE) {
+                            res_k = k + 1u;
+                            res_n = take - 1u;
+                        }
+                    }
                     const uint32_t gpos = (k >> kGroupLog2) * 8u + sh;
                     if (gpos < n_groups) {
                         const uint32_t u = order[gpos] * kGroup + (k & (kGroup - 1u));
                         if (u < n_units) { unit = u; break; }
                         continue;   // past the end of the last, partial group
                     }
+                    if (COARSE) res_k = res_n = 0;   // this shard is empty: the next one starts one unit at a time
                 } else {
+                    const uint32_t sh = (shard + probe) & 7u;
                     const uint32_t lo = sh * per_shard, hi = min(lo + per_shard, n_units);
                     if (lo < hi) {
                         const uint32_t u = lo + atomicAdd(&heads[sh * 32], 1u);
@@ -353,6 +373,9 @@ RTX_D void order_units(UnitOrder* uo) {
     for (uint32_t w = 0; w < (t >> 6); ++w) base += wave_sum[w];
     for (int k = 0; k < kOrderClasses; ++k) offs[t * kOrderClasses + k] += base;
     __syncthreads();
+    // groups in the eight dearest half-octave classes (cost >= 1/16 of the dearest): where class 8 starts in `order`
+    static_assert(kOrderClasses == 16, "class 8 is four octaves below the dearest group");
+    const uint32_t dear_groups = (t == 0) ? offs[8 * kOrderThreads] : 0u;
     if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
@@ -368,7 +391,11 @@ RTX_D void order_units(UnitOrder* uo) {
         }
     }
     __syncthreads();
-    if (t == 0) uo->n_order = n_units;
+    if (t == 0) {
+        // groups in the eight dearest half-octave classes (cost >= 1/16 of the dearest) come first in `order`
+        uo->fine_units = ((dear_groups + 7u) / 8u) * kGroup;   // per shard: sorted positions are dealt round-robin to 8 shards
+        uo->n_order = n_units;
+    }
     __syncthreads();
 }
 
@@ -400,7 +427,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void 
     UnitQueue uq;
     uq.init(&ctl->unit_head[0][0][0], n, uo);
     uq.announce();
-    for (uint32_t unit = uq.next(); unit != 0xffffffffu; unit = uq.next()) {
+    for (uint32_t unit = uq.next<true>(); unit != 0xffffffffu; unit = uq.next<true>()) {
         const unsigned long long unit_start = wall_clock64();
         ++ws.units;
         const uint32_t i = unit * 64 + (threadIdx.x & 63);
