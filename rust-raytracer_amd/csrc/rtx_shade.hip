@@ -302,6 +302,12 @@ struct UnitQueue {
 // of 256 threads; the shading kernel that follows a traversal launch gives it to one of its
 // workgroups, which costs no launch and hides behind the other workgroups.
 constexpr int kOrderThreads = RTX_BLOCK, kOrderClasses = 16;
+// Half-octave code of a cost: 2 * floor(log2 c) + the bit below the leading one (0 for c <= 1), at most 63.
+RTX_D uint32_t cost_code(uint32_t c) {
+    c = max(c, 1u);
+    const int e = 31 - __clz((int)c);
+    return (uint32_t)(2 * e) + ((e > 0) ? ((c >> (e - 1)) & 1u) : 0u);
+}
 RTX_D void order_units(UnitOrder* uo) {
     __shared__ uint32_t offs[kOrderClasses * kOrderThreads];   // [class][thread]: count, then start position
     __shared__ uint32_t wave_sum[kOrderThreads / 64];
@@ -316,42 +322,45 @@ RTX_D void order_units(UnitOrder* uo) {
     }
     uint32_t* cost = uo->cost();
     uint32_t* order = uo->order();
-    const uint32_t per = (n + kOrderThreads - 1) / kOrderThreads;
+    const uint32_t per = (((n + kOrderThreads - 1) / kOrderThreads) + 3u) & ~3u;   // a multiple of 4: a thread's costs are whole 16-byte words
     const uint32_t lo = min(t * per, n), hi = min(lo + per, n);   // thread t sorts the groups [lo, hi)
-    if (t == 0) s_max = 1;
+    if (t == 0) s_max = 0;
     for (int k = 0; k < kOrderClasses; ++k) offs[k * kOrderThreads + t] = 0;
     __syncthreads();
-    // A thread's costs are read once, with independent loads, when they fit its registers (the usual case):
-    // the sort runs inside a shading kernel that may be short, so its own latency counts.
-    constexpr uint32_t kHeld = 16;
+    // A thread's costs are read once, four per load and all loads independent, and kept as one-byte codes when they
+    // fit its registers (up to 16384 groups: four 1080p frames): the sort runs inside a shading kernel that may be
+    // short, so its own latency counts. cost[] is padded to a multiple of 4 entries (see unit_order).
+    constexpr uint32_t kHeld = 16;   // registers: 4 codes each
     uint32_t held[kHeld];
-    const bool fits = per <= kHeld;
+    const bool fits = per <= 4 * kHeld;
+    uint32_t mx = 0;
     if (fits) {
 #pragma unroll
-        for (uint32_t k = 0; k < kHeld; ++k) held[k] = (lo + k < hi) ? cost[lo + k] : 0u;
-    }
-    uint32_t mx = 1;
-    if (fits) {
+        for (uint32_t k = 0; k < kHeld; ++k) {
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            if (lo + 4 * k < hi) c = *reinterpret_cast<const uint4*>(cost + lo + 4 * k);
+            held[k] = cost_code(c.x) | (cost_code(c.y) << 8) | (cost_code(c.z) << 16) | (cost_code(c.w) << 24);
+        }
 #pragma unroll
-        for (uint32_t k = 0; k < kHeld; ++k) mx = max(mx, held[k]);
+        for (uint32_t k = 0; k < kHeld; ++k)
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if (lo + 4 * k + b < hi) mx = max(mx, (held[k] >> (8 * b)) & 0xffu);
     } else {
-        for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost[u]);
+        for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost_code(cost[u]));
     }
     atomicMax(&s_max, mx);
     __syncthreads();
-    const int top = 2 * (31 - __clz((int)s_max)) + 1;
-    auto cls = [top](uint32_t c) {   // 0 = the half octave of the largest cost
-        c = max(c, 1u);
-        const int e = 31 - __clz((int)c);
-        const int half = (e > 0) ? (int)((c >> (e - 1)) & 1u) : 0;
-        return min(kOrderClasses - 1, top - (2 * e + half));
-    };
+    const int top = (int)(s_max | 1u);   // class 0 = the upper half of the largest cost's octave
+    auto cls = [top](uint32_t code) { return min(kOrderClasses - 1, top - (int)code); };
     if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k)
-            if (lo + k < hi) ++offs[cls(held[k]) * kOrderThreads + t];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if (lo + 4 * k + b < hi) ++offs[cls((held[k] >> (8 * b)) & 0xffu) * kOrderThreads + t];
     } else {
-        for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost[u]) * kOrderThreads + t];
+        for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost_code(cost[u])) * kOrderThreads + t];
     }
     __syncthreads();
     // Exclusive scan of the class-major, thread-minor sequence in place; thread t scans the
@@ -379,14 +388,14 @@ RTX_D void order_units(UnitOrder* uo) {
     if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
-            if (lo + k < hi) {
-                order[offs[cls(held[k]) * kOrderThreads + t]++] = lo + k;
-                cost[lo + k] = 0;
-            }
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if (lo + 4 * k + b < hi) order[offs[cls((held[k] >> (8 * b)) & 0xffu) * kOrderThreads + t]++] = lo + 4 * k + b;
+            if (lo + 4 * k < hi) *reinterpret_cast<uint4*>(cost + lo + 4 * k) = make_uint4(0u, 0u, 0u, 0u);
         }
     } else {
         for (uint32_t u = lo; u < hi; ++u) {
-            order[offs[cls(cost[u]) * kOrderThreads + t]++] = u;
+            order[offs[cls(cost_code(cost[u])) * kOrderThreads + t]++] = u;
             cost[u] = 0;
         }
     }
@@ -591,18 +600,30 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             }
             const uint32_t node = run + before + pre[k];
             run += row;
-            if ((int)hit[k].x < 0) {
+            if (pg.enabled && out.direct_w) {   // block-uniform: black for the primary rays that missed
+                // A wavefront's 64 rays are one 8x8 tile and 8 consecutive lanes one row of it: 24 bytes of the
+                // image. A row that missed completely is written as six words, any other miss as three bytes.
                 const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
-                if (pg.enabled && out.direct_w && i < n) {
-                    float4 o4, d4;
-                    primary_ray(pg, i, o4, d4);
-                    if (f2u(d4.w) & RTX_RAY_VALID) {
-                        uint8_t* px = out.rgb + out.pixel(f2u(o4.w)) * 3;
-                        px[0] = px[1] = px[2] = 0;
-                    }
+                bool black = false;
+                size_t pix = 0;
+                if (i < n && (int)hit[k].x < 0) {
+                    const uint32_t g = (uint32_t)pg.first + i;   // the ray's link, as in OutMap::pixel
+                    const uint32_t frame = (out.frames > 1) ? g / out.rays_per_frame : 0u;
+                    const uint32_t fl = g - frame * out.rays_per_frame;
+                    const uint32_t x = ((fl >> 6) % out.tiles_x) * RTX_TILE + (fl & 7u), y = ((fl >> 6) / out.tiles_x) * RTX_TILE + ((fl >> 3) & 7u);
+                    black = x < pg.cam.w && y < pg.cam.h;   // the frames of a batch have one size
+                    pix = (size_t)frame * out.frame_pixels + (size_t)y * out.direct_w + x;
                 }
-                continue;
+                const uint32_t row = (uint32_t)(__ballot(black) >> (lane & 56)) & 0xffu;
+                uint8_t* first = out.rgb + (pix - (uint32_t)(lane & 7)) * 3;
+                if (row == 0xffu && ((uintptr_t)first & 3u) == 0) {
+                    if ((lane & 7) < 6) reinterpret_cast<uint32_t*>(first)[lane & 7] = 0u;
+                } else if (black) {
+                    uint8_t* px = out.rgb + pix * 3;
+                    px[0] = px[1] = px[2] = 0;
+                }
             }
+            if ((int)hit[k].x < 0) continue;
             if (node >= wk.cap_rays || pool_base + node >= wk.cap_pool) {
                 ctl->overflow = 1;
                 continue;
@@ -1216,7 +1237,7 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
 // option is off or the allocation fails (the launch then uses index order).
 UnitOrder* unit_order(rtx_context* ctx, uint32_t kind, uint32_t batch_index, uint64_t cap_groups) {
     if (!ctx->opt_cost_order || batch_index >= 64 || cap_groups == 0 || cap_groups > (1u << 26)) return nullptr;
-    const uint64_t cap_units = cap_groups;   // array length
+    const uint64_t cap_units = (cap_groups + 3u) & ~(uint64_t)3u;   // array length: order_units reads and clears costs four at a time
     const uint64_t key = ((uint64_t)kind << 40) | ((uint64_t)batch_index << 32) | cap_groups;
     for (auto& e : ctx->order_bufs)
         if (e.first == key) return (UnitOrder*)e.second;
