@@ -907,7 +907,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
                     const float* term = wk.shadow + (size_t)first_slot(light, j, wk.n_samples) * wk.cap_rays + node;
                     float shade = 0.0f;                               // lib.rs:112-138
                     for (uint32_t smp = 0; smp < n; ++smp) shade += term[(size_t)smp * wk.cap_rays];
-                    shade = clamp01(shade / (float)n);
+                    shade = clamp01(n != 1u ? shade / (float)n : shade);
                     direct_light = direct_light + direct_lightning(light, point, normal, dir, cd, ks, kt, shininess,
                                                                    Col{shade, shade, shade}, fattj, n, area ? rng_push(kl, 2) : 0ull);
                 }

@@ -176,7 +176,8 @@ RTX_D Col direct_lightning(const DevLight& l, V3 point, V3 normal, V3 ray_dir, C
         const bool matte = ks.r == 0.0f && ks.g == 0.0f && ks.b == 0.0f && t <= 1.0f && q >= 0.0f;
         const Col specular_light = matte ? col_new() : col_mult(ks, powf(t, q));
         Col sample = direct_light * (diffuse_light + specular_light);
-        sample = col_init(sample.r / nf, sample.g / nf, sample.b / nf);
+        if (n != 1u) sample = col_init(sample.r / nf, sample.g / nf, sample.b / nf);   // x / 1.0f is x: three divisions less per point light
+        else sample = col_init(sample.r, sample.g, sample.b);
         lightning = lightning + sample;
     }
     return lightning;

@@ -191,7 +191,7 @@ constexpr float kSphereK = RTX_SPHERE_K;
 template <bool WIDEN>
 RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, uint32_t wfy, uint32_t wfz, uint32_t nchild,
                        const RayBox& rb, float limit, float sx, float sy, float sz, float lnx, float lny, float lnz, float lfx,
-                       float lfy, float lfz, const float* e, float* t) {
+                       float lfy, float lfz, const float* e, float* t, int* hits = nullptr) {
     const float inf = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -209,6 +209,7 @@ RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, u
         const float hi = fminf(fminf(fminf(fx, fy), fz), limit);
         const bool hit = ((uint32_t)k < nchild) & (lo <= hi);   // bitwise: no branches
         t[k] = hit ? lo : inf;
+        if (hits) hits[k] = hit;
     }
 }
 
@@ -243,6 +244,7 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
     const uint32_t wnz = ngz ? C.y : B.z, wfz = ngz ? B.z : C.y;
     const float inf = __builtin_inff();
     float t[4];
+    int hk[4] = {0, 0, 0, 0};   // SORT = false: which children the ray enters (a range that starts at +inf counts: visiting more is always safe)
     int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
     // spheres below: widen their children (see kSphereK). The branch is taken by the whole wavefront or not at all
     // (a vote), so that wavefronts away from any sphere skip the widening arithmetic instead of computing it masked.
@@ -262,9 +264,9 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
             const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
             e[k] = ((meta >> 31) != 0u && hbits != 0x7c00u) ? kd2 * __builtin_amdgcn_rcpf(den) * 1.002f : 0.0f;
         }
-        node4_slabs<true>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, e, t);
+        node4_slabs<true>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, e, t, SORT ? nullptr : hk);
     } else {
-        node4_slabs<false>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, nullptr, t);
+        node4_slabs<false>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, nullptr, t, SORT ? nullptr : hk);
     }
 #define RTX_CE(i, j)                                   \
     do {                                               \
@@ -291,7 +293,7 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
         if (t[0] < inf) return r[0];
     } else {
         // any order will do: the lowest hit child is next, the others are pushed from the highest down
-        const int h0 = t[0] < inf, h1 = t[1] < inf, h2 = t[2] < inf, h3 = t[3] < inf;
+        const int h0 = hk[0], h1 = hk[1], h2 = hk[2], h3 = hk[3];
         const int p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;   // pushed: hit, and not the lowest hit
         if (sp + 3 <= RTX_STACK_LDS) {
             if (p3) st.base[sp * RTX_BLOCK] = r[3];

@@ -227,3 +227,32 @@ def test_batch_limits(rtx, gpu_ctx_factory):
         ctx.render_frames(2, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)      # 8192 rays do not fit one batch
     assert e.value.status == 1 and "batch" in str(e.value)
     ctx.render_frames(1, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)          # a single frame may still be cut into batches
+
+
+@pytest.mark.parametrize("w,h", [(101, 67), (64, 64), (90, 70), (8, 8), (7, 5), (1, 1)])
+def test_row_major_frame_overwrites_a_dirty_buffer(rtx, w, h):
+    """bmp::Image::new gives black to every pixel trace_rays does not set (src/lib.rs:260-271): the row-major outputs
+    need no cleared buffer, whether an image row starts on a word boundary (w * 3 divisible by 4) or not, and nothing
+    outside the frame is touched."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test05"))
+    cams = _cameras(rtx, flat, 2)
+    n = h * w * 3
+    with rtx.Context(0) as ctx:
+        ctx.set_scene(flat)
+        ctx.build()
+        clean = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        ctx.render_device(w, h, 6, 1, clean.data_ptr())
+        guard = 64 if w % 2 == 0 else 61      # also an image that does not start on a word boundary
+        dirty = torch.full((n + 2 * guard,), 0xAB, dtype=torch.uint8, device="cuda:0")
+        ctx.render_device(w, h, 6, 1, dirty.data_ptr() + guard)
+        torch.cuda.synchronize()
+        assert torch.equal(dirty[guard:guard + n], clean)
+        assert bool((dirty[:guard] == 0xAB).all()) and bool((dirty[guard + n:] == 0xAB).all())
+        # a batch of two frames, second camera moved: frame 0 (the scene's own camera) is the frame above
+        both = torch.full((2 * n + 2 * guard,), 0xCD, dtype=torch.uint8, device="cuda:0")
+        ctx.render_frames(2, cams, w, h, 6, 1, 0, 1, both.data_ptr() + guard, True)
+        torch.cuda.synchronize()
+        assert torch.equal(both[guard:guard + n], clean)
+        assert bool((both[:guard] == 0xCD).all()) and bool((both[guard + 2 * n:] == 0xCD).all())
+        assert not bool((both[guard + n:guard + 2 * n] == 0xCD).all())
