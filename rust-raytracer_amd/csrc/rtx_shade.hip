@@ -42,7 +42,7 @@ enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_REFRACT, ST_SKIPPED, ST_NODES, 
 struct Work {
     RayQueue q[2];
     uint32_t cap_rays;
-    float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir, pool slot) (cd, -)
+    float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir, pool slot) (cd: written and read only where it is a blend of vertex materials)
     // Shadow terms, [n_slots][cap_rays]: one slot per sample of shadow_scalar's loop (lib.rs:113-135).
     // Light j owns slots first_slot(j) .. + n_j - 1, n_j = n_samples for an area light, else 1,
     // first_slot(j) = j + area_before(j) * (n_samples - 1).
@@ -640,11 +640,11 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             const HitGeom g = hit_geometry(s, (int)hit[k].x, o, d, u2f(hit[k].y), true);
             panic |= g.panic;
             const uint32_t slot = pool_base + node;
-            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u);
+            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u) | (g.blended ? 8u : 0u);
             wk.nP[node] = make_float4(g.p.x, g.p.y, g.p.z, u2f(g.mat0));
             wk.nN[node] = make_float4(g.n.x, g.n.y, g.n.z, u2f(nflags));
             wk.nV[node] = make_float4(d.x, d.y, d.z, u2f(slot));
-            wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);
+            if (g.blended) wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);   // any other colour is the material's: k_shade_b looks it up
             wk.pLink[slot] = f2u(o4.w);
             if (wk.pKey) {   // the node's sampling key: hash of the pixel, extended along the path through the ray tree
                 const uint32_t link = f2u(o4.w);
@@ -884,12 +884,16 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
         V3 ro0, rd0, ro1, rd1;
         uint32_t slot = 0;
         if (node < nn) {
-            const float4 p4 = wk.nP[node], n4 = wk.nN[node], v4 = wk.nV[node], c4 = wk.nC[node];
+            const float4 p4 = wk.nP[node], n4 = wk.nN[node], v4 = wk.nV[node];
             const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z), dir = v3(v4.x, v4.y, v4.z);
-            const Col cd = Col{c4.x, c4.y, c4.z};
             const uint32_t mat0 = f2u(p4.w), nflags = f2u(n4.w);
             slot = f2u(v4.w);
             const rtx_material* m = material_or_null(s, mat0);
+            Col cd = m ? col_raw(m->diffuse) : col_new();   // as hit_geometry sets it, unless the colour is a blend of vertex materials
+            if (nflags & 8u) {
+                const float4 c4 = wk.nC[node];
+                cd = Col{c4.x, c4.y, c4.z};
+            }
             const float kt = m ? m->transparency : 0.0f;
             const float shininess = m ? m->shininess : 0.0f;
             const Col ks = m ? col_raw(m->specular) : col_new();

@@ -11,6 +11,7 @@ struct HitGeom {
     Col cd;         // Intersection::color            (intersection.rs:30-32)
     uint32_t mat0;  // Intersection::material = materials[0] (poly.rs:181-183, sphere.rs:105-107)
     bool panic;     // the reference would have panicked (poly.rs:84-86 or an index past the material list)
+    bool blended;   // cd is a blend of three vertex materials (poly.rs:91-94); otherwise it is materials[mat0].diffuse, or black without that material
 };
 
 RTX_D V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
@@ -33,6 +34,7 @@ RTX_D void weighted_areas(V3 p0, V3 p1, V3 p2, V3 point, float& a0, float& a1, f
 RTX_D HitGeom hit_geometry(const DevScene& s, int prim_id, V3 o, V3 d, float t, bool want_color) {
     HitGeom g;
     g.panic = false;
+    g.blended = false;
     g.p = o + vmult(d, t);
     g.cd = col_new();
     const uint32_t ref = s.prim_ref[prim_id];
@@ -74,6 +76,7 @@ RTX_D HitGeom hit_geometry(const DevScene& s, int prim_id, V3 o, V3 d, float t, 
             const Col db = mb ? col_raw(mb->diffuse) : col_new();
             const Col dc = mc ? col_raw(mc->diffuse) : col_new();
             g.cd = col_mult(da, a2) + col_mult(db, a1) + col_mult(dc, a0);
+            g.blended = true;
         } else {                                // poly.rs:201
             const rtx_material* m = material_or_null(s, m0);
             if (m) g.cd = col_raw(m->diffuse); else g.panic = true;
