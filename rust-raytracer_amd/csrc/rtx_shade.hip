@@ -42,7 +42,7 @@ enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_REFRACT, ST_SKIPPED, ST_NODES, 
 struct Work {
     RayQueue q[2];
     uint32_t cap_rays;
-    float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir, pool slot) (cd: written and read only where it is a blend of vertex materials)
+    float4 *nP, *nN, *nV, *nC;   // per-level node arrays: (point, mat0) (normal, flags) (ray dir: only for nodes with a specular term or children) (cd: written and read only where it is a blend of vertex materials)
     // Shadow terms, [n_slots][cap_rays]: one slot per sample of shadow_scalar's loop (lib.rs:113-135).
     // Light j owns slots first_slot(j) .. + n_j - 1, n_j = n_samples for an area light, else 1,
     // first_slot(j) = j + area_before(j) * (n_samples - 1).
@@ -640,10 +640,17 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             const HitGeom g = hit_geometry(s, (int)hit[k].x, o, d, u2f(hit[k].y), true);
             panic |= g.panic;
             const uint32_t slot = pool_base + node;
-            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u) | (g.blended ? 8u : 0u);
+            // The ray's direction enters the node's colour through the specular term and the children only. A material
+            // with ks = 0, kt = 0 and a moderate exponent has neither (rj . v <= 1 + a few ulp, so powf stays finite and
+            // ks * powf is exactly zero, see direct_lightning): such a node does without the direction.
+            const rtx_material* gm = material_or_null(s, g.mat0);
+            const float gq = (gm ? gm->shininess : 0.0f) * 128.0f;
+            const bool plain = (!gm || (gm->specular[0] == 0.0f && gm->specular[1] == 0.0f && gm->specular[2] == 0.0f && gm->transparency == 0.0f)) &&
+                               gq >= 0.0f && gq <= 65536.0f;
+            const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u) | (g.blended ? 8u : 0u) | (plain ? 0u : 16u);
             wk.nP[node] = make_float4(g.p.x, g.p.y, g.p.z, u2f(g.mat0));
             wk.nN[node] = make_float4(g.n.x, g.n.y, g.n.z, u2f(nflags));
-            wk.nV[node] = make_float4(d.x, d.y, d.z, u2f(slot));
+            if (!plain) wk.nV[node] = make_float4(d.x, d.y, d.z, 0.0f);
             if (g.blended) wk.nC[node] = make_float4(g.cd.r, g.cd.g, g.cd.b, 0.0f);   // any other colour is the material's: k_shade_b looks it up
             wk.pLink[slot] = f2u(o4.w);
             if (wk.pKey) {   // the node's sampling key: hash of the pixel, extended along the path through the ray tree
@@ -870,6 +877,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
     if (sort_uo && blockIdx.x == 0) order_units(sort_uo);   // costs of the shadow launch just finished
     if (block_sees_overflow(ctl)) return;
     const uint32_t nn = ctl->n_nodes;
+    const uint32_t pool_base = ctl->pool_base;   // node k of this level keeps slot pool_base + k of the pool (k_shade_a)
     if (finalize && blockIdx.x == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
     const RayQueue q = wk.q[qo];
     const uint32_t stride = gridDim.x * RTX_BLOCK;
@@ -884,10 +892,15 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
         V3 ro0, rd0, ro1, rd1;
         uint32_t slot = 0;
         if (node < nn) {
-            const float4 p4 = wk.nP[node], n4 = wk.nN[node], v4 = wk.nV[node];
-            const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z), dir = v3(v4.x, v4.y, v4.z);
+            const float4 p4 = wk.nP[node], n4 = wk.nN[node];
+            const V3 point = v3(p4.x, p4.y, p4.z), normal = v3(n4.x, n4.y, n4.z);
             const uint32_t mat0 = f2u(p4.w), nflags = f2u(n4.w);
-            slot = f2u(v4.w);
+            V3 dir = v3(0.0f, 0.0f, 0.0f);   // not stored for nodes whose colour and children do not depend on it (k_shade_a)
+            if (nflags & 16u) {
+                const float4 v4 = wk.nV[node];
+                dir = v3(v4.x, v4.y, v4.z);
+            }
+            slot = pool_base + node;
             const rtx_material* m = material_or_null(s, mat0);
             Col cd = m ? col_raw(m->diffuse) : col_new();   // as hit_geometry sets it, unless the colour is a blend of vertex materials
             if (nflags & 8u) {
