@@ -612,6 +612,31 @@ def main():
                                         "three_contexts_ms_per_frame": dt3 * 1e3,
                                         "three_contexts_Mrays_s": (total_traced / frames) / dt3 / 1e6,
                                         "frame_equals_headline_frame": bool(torch.equal(bufs[299 % 6], image[:h * w * 3]))}
+                if fpb > 1:
+                    # The headline's batches alternating between two contexts (streams): one batch's kernel tails and
+                    # single-workgroup kernels overlap the other batch's kernels. Not the headline because overlapping
+                    # kernels have no launch duration of their own to hold against a roofline.
+                    pair = [ctx, extra[0]]
+                    bufs_b = [torch.zeros(fpb * h * w * 3, dtype=torch.uint8, device=dev) for _ in range(4)]
+                    torch.cuda.synchronize()
+
+                    def run2(n):
+                        for k in range(n):
+                            if k >= 2:
+                                pair[k % 2].render_wait()
+                            pair[k % 2].render_frames_async(fpb, None, w, h, args.depth, 10, 0, 1, bufs_b[k % 4].data_ptr(), True)
+                        for k in range(n, n + 2):
+                            pair[k % 2].render_wait()
+                        torch.cuda.synchronize()
+                    run2(8)
+                    n2 = max(300 // fpb, 8)
+                    t2 = time.perf_counter()
+                    run2(n2)
+                    dt2 = (time.perf_counter() - t2) / (n2 * fpb)
+                    out["supplementary"]["batches_on_two_contexts"] = {
+                        "ms_per_frame": dt2 * 1e3, "Mrays_s": (total_traced / frames) / dt2 / 1e6,
+                        "frames_equal_headline_frames": bool(torch.equal(bufs_b[(n2 - 1) % 4], image[:fpb * h * w * 3]))}
+                    del bufs_b
                 ctx.set_option("kernel_timing", 1)
                 for c in extra:
                     c.close()
