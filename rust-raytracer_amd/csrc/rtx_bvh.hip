@@ -675,7 +675,10 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, uint32_t level, const
 }
 
 // Traversal records, in `order` (sorted ids) or in id order when order == nullptr.
-__global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32_t* __restrict__ order, PrimRec* __restrict__ recs) {
+// flat / n_flat (with a tree): positions of the records of triangles without an area to speak of (DevScene::always),
+// |e1 x e2| <= 1e-3 |e1| |e2|; the list holds at most s.n_prims entries, n_flat counts them.
+__global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32_t* __restrict__ order, PrimRec* __restrict__ recs,
+                                                         uint32_t* __restrict__ flat, uint32_t* __restrict__ n_flat) {
     for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < s.n_prims; j += gridDim.x * kThreads) {
         const uint32_t id = order ? order[j] : j;
         const uint32_t ref = s.prim_ref[id];
@@ -694,9 +697,19 @@ __global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32
             rc.q0 = make_float4(v0.x, v0.y, v0.z, __uint_as_float(id));
             rc.q1 = make_float4(e1.x, e1.y, e1.z, __uint_as_float(0u));
             rc.q2 = make_float4(e2.x, e2.y, e2.z, 0.0f);
+            if (flat) {
+                const V3 c = vcross(e1, e2);
+                if (vdot(c, c) <= 1e-6f * vdot(e1, e1) * vdot(e2, e2)) flat[atomicAdd(n_flat, 1u)] = j;   // false for NaN: such a triangle is never hit
+            }
         }
         recs[j] = rc;
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_copy_recs(const PrimRec* __restrict__ recs, const uint32_t* __restrict__ which, uint32_t n,
+                                                         PrimRec* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = recs[which[i]];
 }
 
 // prim_ref from device-resident index arrays (rtx_scene_set_device): ref[id] = element | kind bit, with the
@@ -804,6 +817,8 @@ int rtx_bvh_build(rtx_context* ctx) {
     ctx->build_store.reset();      // a clone that shares the old tree keeps it alive
     auto store = std::make_shared<DevStore>();
     ctx->built = false;
+    s.always = nullptr;
+    s.n_always = 0;
     rtx_build_stats bs{};
     bs.n_prims = n;
     bs.upload_ms = ctx->build_stats.upload_ms;
@@ -882,7 +897,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > (uint32_t)leaf_max)
                         : (ctx->opt_force_mode == 1) ? false : (n > RTX_EXHAUSTIVE_MAX);
     if (!want_bvh) {
-        if (n > 0) hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, (const uint32_t*)nullptr, recs);
+        if (n > 0) hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, (const uint32_t*)nullptr, recs, (uint32_t*)nullptr, (uint32_t*)nullptr);
         s.recs = recs;
         s.nodes = nullptr;
         s.n_nodes = 0;
@@ -948,8 +963,12 @@ int rtx_bvh_build(rtx_context* ctx) {
         // well-spread primitives, a launch for a level that does not exist ends at once, and the build's one wait -- after
         // everything is enqueued -- tells whether a deeper tree needs further rounds.
         TRY(tmp.get(&nodes_tmp, n - 1));
+        uint32_t *flat = nullptr, *n_flat = nullptr;
+        TRY(tmp.get(&flat, n));
+        TRY(tmp.get(&n_flat, 1));
+        TRY_HIP(hipMemsetAsync(n_flat, 0, 4, st));
         std::vector<LevelInfo> hl(kMaxLevels + 2);
-        uint32_t height = 0, bad_boxes = 0, launched = 0;
+        uint32_t height = 0, bad_boxes = 0, launched = 0, flat_count = 0;
         {
             const int root = 0;
             const LevelInfo first{1u, 0u};
@@ -966,9 +985,10 @@ int rtx_bvh_build(rtx_context* ctx) {
                 width = std::min<uint64_t>(width * 4, n);
             }
             if (!recs_made) {
-                hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs);
+                hipLaunchKernelGGL(k_make_recs, dim3(grid_for(n)), dim3(kThreads), 0, st, s, sids, recs, flat, n_flat);
                 recs_made = true;
             }
+            TRY_HIP(hipMemcpyAsync(&flat_count, n_flat, 4, hipMemcpyDeviceToHost, st));
             if (mismatches) TRY_HIP(hipMemcpyAsync(&bad_boxes, mismatches, 4, hipMemcpyDeviceToHost, st));
             TRY_HIP(hipMemcpyAsync(&height, root_height, 4, hipMemcpyDeviceToHost, st));
             TRY_HIP(hipMemcpyAsync(hl.data(), lvl, hl.size() * sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
@@ -987,6 +1007,13 @@ int rtx_bvh_build(rtx_context* ctx) {
         BvhNode* nodes = nullptr;
         TRY(dev_alloc(ctx, store->ptrs, &nodes, (size_t)n_nodes));
         TRY_HIP(hipMemcpyAsync(nodes, nodes_tmp, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToDevice, st));
+        if (flat_count) {   // rare: see DevScene::always
+            PrimRec* always = nullptr;
+            TRY(dev_alloc(ctx, store->ptrs, &always, (size_t)flat_count));
+            hipLaunchKernelGGL(k_copy_recs, dim3((flat_count + kThreads - 1) / kThreads), dim3(kThreads), 0, st, recs, flat, flat_count, always);
+            s.always = always;
+            s.n_always = flat_count;
+        }
         bs.n_nodes = (uint32_t)n_nodes;
         bs.n_leaves = (uint32_t)n_leaves;
         bs.max_depth = height;   // height of the binary tree; the 4-wide tree has about half of it

@@ -48,7 +48,8 @@ constexpr unsigned long long kCoopMiss = ((unsigned long long)0x7f800000u << 32)
 // Any-hit (ANY = true):  out_id = 1 when some primitive occludes the light at distance dist_light
 //                        (dist_light < 0: any hit occludes), else 0.
 // SPH: the scene holds spheres (false: triangle-only code, see record_hit).
-template <bool ANY, bool SPH = true>
+// ALWAYS: the scene holds triangles that every ray has to test (DevScene::always); kernels without them do not carry the loop.
+template <bool ANY, bool SPH = true, bool ALWAYS = false>
 RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, V3 d, float dist_light, TravStack& st, CoopLds& L, int threshold,
                       float& out_t, int& out_id) {
     const int lane = threadIdx.x & 63;
@@ -65,6 +66,14 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
             }
         } else {
             cur = 0;
+            // triangles whose test answers to rounding noise rather than to where the ray goes (DevScene::always): usually none
+            for (uint32_t i = 0; ALWAYS && i < s.n_always; ++i) {
+                if (ANY) {
+                    if (any_record<false>(s.always, i, o, d, dist_light)) { best_id = 1; cur = kRefDone; break; }
+                } else {
+                    test_record<false>(s.always, i, o, d, best_t, best_id);
+                }
+            }
         }
     }
     // any-hit: boxes beyond the light never hold an occluder (vdistance(o, o + d*t) carries an absolute rounding error of a few ulp of |o|)

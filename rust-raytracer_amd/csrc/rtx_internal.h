@@ -81,6 +81,11 @@ struct DevScene {
     // traversal-side arrays
     const PrimRec* recs;        // [n_prims]
     const BvhNode* nodes;       // [n_nodes] in level order (node 0 is the root), one slot per node
+    // Triangles without an area to speak of (two edges within 1e-3 rad of parallel, or a zero edge): the determinant of
+    // poly.rs:149-153 is rounding noise for them, so the reference's test can report a hit for a ray that passes nowhere
+    // near the triangle, which no box can promise to contain. Copies of their records: every ray tests them all.
+    const PrimRec* always;      // [n_always]
+    uint32_t n_always;
     // Rays whose origin lies outside the cube |o - safe_c|_inf <= safe_r take the
     // exhaustive loop: the sphere padding of the BVH is only proven inside it.
     float safe_c[3];

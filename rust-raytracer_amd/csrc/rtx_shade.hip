@@ -419,7 +419,7 @@ static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_sh
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-template <bool SPH>
+template <bool SPH, bool ALWAYS = false>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void 
         }
         int id = -1;
         float t = 0.0f;
-        coop_trace<false, SPH>(s, tc, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
+        coop_trace<false, SPH, ALWAYS>(s, tc, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
         if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
         const uint64_t hits = __ballot(i < n && id >= 0);
@@ -797,7 +797,7 @@ struct ShadowTask {
     }
 };
 
-template <bool ANY, bool AREA, bool SPH>
+template <bool ANY, bool AREA, bool SPH, bool ALWAYS = false>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(shadow_waves(ANY, AREA, SPH)) void k_shadow(DevScene s, Work wk, uint32_t depth, uint32_t n_slots, UnitOrder* uo) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
@@ -843,11 +843,11 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(shadow_waves(ANY, AREA, S
         st.t_setup += __builtin_readcyclecounter() - su0;
 #endif
         if (ANY) {
-            coop_trace<true, SPH>(s, tc, live, o, d, dl, st, coop, s.tune[0], t, id);
+            coop_trace<true, SPH, ALWAYS>(s, tc, live, o, d, dl, st, coop, s.tune[0], t, id);
             if (live) task.finish_any(id != 0);
         } else {
             while (__ballot(live)) {   // all lanes stay in the loop: the traversal is cooperative
-                coop_trace<false, SPH>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+                coop_trace<false, SPH, ALWAYS>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
                 if (live) live = task.finish_closest(id, t, o, d);
             }
         }
@@ -1215,9 +1215,12 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
 // launch, because events recorded between launches each cost the stream several idle microseconds.
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(ctx->ds.n_spheres != 0))), block(RTX_BLOCK);
+    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(ctx->ds)))), block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
-    if (ctx->ds.n_spheres) {
+    if (ctx->ds.n_always) {
+        if (t0 || t1) hipExtLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        else hipLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+    } else if (ctx->ds.n_spheres) {
         if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
         else hipLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
     } else {
@@ -1229,7 +1232,10 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
 template <bool ANY, bool AREA>
 void launch_shadow_kernel(dim3 grid, hipStream_t st, hipEvent_t t0, hipEvent_t t1, const DevScene& s, const Work& wk, uint32_t depth,
                           uint32_t n_slots, UnitOrder* uo) {
-    if (s.n_spheres) {
+    if (s.n_always) {
+        if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA, true, true>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
+        else hipLaunchKernelGGL((k_shadow<ANY, AREA, true, true>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
+    } else if (s.n_spheres) {
         if (t0 || t1) hipExtLaunchKernelGGL((k_shadow<ANY, AREA, true>), grid, dim3(RTX_BLOCK), 0, st, t0, t1, 0, s, wk, depth, n_slots, uo);
         else hipLaunchKernelGGL((k_shadow<ANY, AREA, true>), grid, dim3(RTX_BLOCK), 0, st, s, wk, depth, n_slots, uo);
     } else {
@@ -1243,7 +1249,7 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
     const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                shadow_waves(any, area, s.n_spheres != 0)));
+                                shadow_waves(any, area, general_kernels(s))));
     if (any && area) launch_shadow_kernel<true, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (any) launch_shadow_kernel<true, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (area) launch_shadow_kernel<false, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
@@ -1408,9 +1414,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         if (s.n_lights > 0) (void)unit_order(ctx, 1, 0, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup);
         const uint64_t key[8] = {((uint64_t)w << 32) | h, ((uint64_t)depth << 32) | samples, ((uint64_t)rank << 32) | world,
                                  (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
-                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(s.n_spheres != 0)) << 32) |
+                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(s))) << 32) |
                                      trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                                 shadow_waves(any_shadow, s.n_area_lights != 0, s.n_spheres != 0)),
+                                                 shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s))),
                                  (uint64_t)(uintptr_t)wk.ctl ^ (cam_hash * 0x9e3779b97f4a7c15ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;

@@ -20,7 +20,7 @@ static std::mutex g_scratch_mutex;
 
 namespace {
 
-template <bool SPH>
+template <bool SPH, bool ALWAYS = false>
 __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n, const float* __restrict__ ori3,
                                                          const float* __restrict__ dir3, int32_t* __restrict__ prim,
                                                          float* __restrict__ tout, int exhaustive) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_intersect(DevScene s, uint64_t n,
         if (exhaustive || !s.uses_bvh) {
             if (live) trace_exhaustive(s, o, d, t, id);
         } else {
-            coop_trace<false, SPH>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
+            coop_trace<false, SPH, ALWAYS>(s, tc, live, o, d, 0.0f, st, coop, s.tune[0], t, id);
         }
         if (live) {
             prim[i] = id;
@@ -63,7 +63,8 @@ int rtx_launch_intersect(rtx_context* ctx, uint64_t n, const float* d_ori3, cons
     const DevScene& s = ctx->ds;
     const int exhaustive = (mode == 1) ? 1 : 0;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + RTX_BLOCK - 1) / RTX_BLOCK, s.spill_stride / RTX_BLOCK);
-    if (s.n_spheres) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, exhaustive);
+    if (s.n_always) hipLaunchKernelGGL((k_intersect<true, true>), dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, exhaustive);
+    else if (s.n_spheres) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, exhaustive);
     else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, exhaustive);
     RTX_HIP(ctx, hipGetLastError());
     return RTX_OK;
@@ -107,7 +108,8 @@ int rtx_launch_intersect_noalloc(rtx_context* ctx, uint64_t n, const float* d_or
     s.spill_entries = RTX_NOALLOC_ENTRIES;
     s.stamps = nullptr;   // the stamp buffer is sized for the context's own grids
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + RTX_BLOCK - 1) / RTX_BLOCK, RTX_NOALLOC_BLOCKS);
-    if (s.n_spheres) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, 0);
+    if (s.n_always) hipLaunchKernelGGL((k_intersect<true, true>), dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, 0);
+    else if (s.n_spheres) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, 0);
     else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(RTX_BLOCK), 0, ctx->stream, s, n, d_ori3, d_dir3, d_prim, d_t, 0);
     RTX_HIP(ctx, hipGetLastError());
     return RTX_OK;

@@ -30,6 +30,9 @@
 constexpr int closest_waves(bool sph) { return sph ? 5 : 6; }
 constexpr int shadow_waves(bool any, bool area, bool sph) { return sph ? ((any && !area) ? 5 : 4) : (any ? 6 : 5); }
 #define RTX_WAVES_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// Which kernels a scene runs on: the triangle-only ones unless it holds spheres or triangles that every ray has to test
+// (DevScene::always; rare enough to share the general kernels, compiled once more with that loop).
+RTX_HD bool general_kernels(const DevScene& s) { return s.n_spheres != 0 || s.n_always != 0; }
 
 RTX_D uint32_t f2u(float f) { return __float_as_uint(f); }
 RTX_D float u2f(uint32_t u) { return __uint_as_float(u); }
