@@ -14,9 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("first,count", [(0, 12), (36, 1), (102, 1), (127, 1), (129, 1), (135, 1), (236, 1), (300, 6)])
-def test_bvh_equals_exhaustive_on_random_scenes(first, count):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bvh.py"), "--first-seed", str(first), "--scenes", str(count),
-                        "--seconds", "100", "--rays", "100000"], capture_output=True, text=True, timeout=110)
+@pytest.mark.parametrize("family,first,count", [(0, 0, 12), (0, 36, 1), (0, 102, 1), (0, 127, 1), (0, 129, 1), (0, 135, 1), (0, 236, 1), (0, 300, 6),
+                                                (1, 0, 16), (1, 200, 8)])
+def test_bvh_equals_exhaustive_on_random_scenes(family, first, count):
+    """Family 1: slivers, rays nearly in the planes of triangles and along their edges, scenes far from the origin, rays
+    tangent to spheres. Rays that lie in a triangle's plane to within rounding are the one documented difference (the
+    reference's answer for them is rounding noise); the tool counts them apart and fails on anything else."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bvh.py"), "--family", str(family), "--first-seed", str(first),
+                        "--scenes", str(count), "--seconds", "100", "--rays", "100000"], capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "scenes with mismatches: 0" in r.stdout
