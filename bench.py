@@ -265,12 +265,13 @@ def main():
     # Frames per batch: a rank's 1/N share of one small frame cannot fill a GPU (its launches are as long as their
     # longest ray chains however few rays they hold), so sharded runs render the shares of several frames at once.
     # Larger launches also lose less at their ends (a launch finishes with its slowest wavefronts while the rest of the
-    # GPU idles), so the 1080p configuration renders 4 frames per batch and GPU -- measured 8.2 / 9.9 / 10.8 / 11.0
-    # Grays/s with 1 / 2 / 4 / 8 frames per batch on one GPU. The 4K and 8K configurations render frame by frame.
+    # GPU idles), so the 1080p configuration renders 8 frames per batch and GPU (the library's limit is 32 frames per batch,
+    # which caps 8 ranks at 4 frames each) -- measured 8.9 / 10.5 / 13.4 / 14.3 Grays/s with 1 / 2 / 4 / 8 frames per
+    # batch on one GPU. The 4K and 8K configurations render frame by frame.
     if args.frames_per_batch > 0:
         fpb = args.frames_per_batch
     elif args.config == 3:
-        fpb = min(4 * world, rtx.MAX_BATCH_FRAMES)
+        fpb = min(8 * world, rtx.MAX_BATCH_FRAMES)
     else:
         fpb = 1
     fps = (fps + fpb - 1) // fpb * fpb      # a step is a whole number of batches

@@ -161,7 +161,7 @@ const char* rtx_last_error(const rtx_context* ctx);
  *                   launches (default 24 = 6 units), byte 1 for shadow launches (default 10 = 2.5 units); small
  *                   launches get fewer workgroups per CU accordingly
  *   "tune2"         most traversal workgroups per CU (1..8, default 4)
- *   "tune3"         primitives per leaf (1..8, default 1; at the next rtx_build)
+ *   "tune3"         primitives per leaf: fixed at 1 (any other value is RTX_ERR_INVALID_ARG)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.
  *   "verify_build"  1 = rtx_build recomputes, in a launch of its own, every inner node's box from its children's and fails

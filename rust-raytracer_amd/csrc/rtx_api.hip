@@ -162,6 +162,7 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
         ctx->opt_force_mode = value;
         ctx->built = false;   // takes effect at the next rtx_build
     } else if (k.size() == 5 && k.compare(0, 4, "tune") == 0 && k[4] >= '0' && k[4] <= '3') {
+        if (k[4] == '3' && value != 1) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "tune3 (primitives per leaf) is fixed at 1");
         ctx->opt_tune[k[4] - '0'] = (int32_t)value;
         for (int i = 0; i < 4; ++i) ctx->ds.tune[i] = ctx->opt_tune[i];
     } else if (k == "graphs") {

@@ -3,8 +3,7 @@
 //   bounds (Shape::get_bbox: poly.rs:122-136, sphere.rs:45-52; centroid: shapes/mod.rs:40-42)
 //   -> Morton keys -> LSD radix sort staged through LDS -> Karras hierarchy
 //   -> bottom-up refit in one launch (arrival counters, agent-scope release / acquire) -> 64-byte traversal
-//   nodes emitted level by level into a dense array (level order), small subtrees collapsed into leaves of
-//   a few primitives (tune3, default RTX_LEAF_MAX).
+//   nodes emitted level by level into a dense array (level order); a leaf is one primitive (RTX_LEAF_MAX).
 // Queries on the result return what the exhaustive loop returns (see
 // rtx_traverse.h); the reference BVH's own tie rule (bvh.rs:134) is not copied.
 #include <algorithm>
@@ -892,7 +891,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     PadParams pp;
     pp.rel = s.pad_rel;
 
-    const int leaf_max = std::min<int>(std::max<int>(ctx->opt_tune[3], 1), 8);
+    const int leaf_max = RTX_LEAF_MAX;   // the traversal kernels test exactly the record a leaf reference points at
     uint32_t levels4 = 0;   // height of the 4-wide tree
     const bool want_bvh = (ctx->opt_force_mode == 2) ? (n > (uint32_t)leaf_max)
                         : (ctx->opt_force_mode == 1) ? false : (n > RTX_EXHAUSTIVE_MAX);

@@ -116,21 +116,17 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
             if (cur >= 0) {
                 cur = node4_step<!ANY, SPH>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : best_t, st, sp, 0, kRefDone);
             } else {
-                const uint32_t leaf = ~(uint32_t)cur;
-                const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+                // a leaf is one primitive, and its record is what was fetched
                 if (ANY) {
-                    bool occ = any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
-                    for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record<SPH>(s.recs, first + k, o, d, dist_light);
-                    if (occ) {
+                    if (any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light)) {
                         best_id = 1;
                         sp = 0;
                     }
                 } else {
                     test_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, best_t, best_id);
-                    for (uint32_t k = 1; k < cnt; ++k) test_record<SPH>(s.recs, first + k, o, d, best_t, best_id);
                 }
 #ifdef RTX_COUNT_STEPS
-                st.leaves += cnt;
+                ++st.leaves;
 #endif
                 cur = (sp == 0) ? kRefDone : st.get(--sp);
             }
@@ -222,12 +218,8 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
                 if (cur >= 0) {
                     cur = node4_step<!ANY, SPH>(f.a, f.b, f.c, f.d, rb, o, ANY ? t_limit : u2f((uint32_t)(key >> 32)), st, sp, bot, kRefDone);
                 } else {
-                    const uint32_t leaf = ~(uint32_t)cur;
-                    const uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
                     if (ANY) {
-                        bool occ = any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light);
-                        for (uint32_t k = 1; k < cnt && !occ; ++k) occ = any_record<SPH>(s.recs, first + k, o, d, dist_light);
-                        if (occ) {
+                        if (any_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, dist_light)) {
                             __hip_atomic_store(&slot[owner], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             sp = bot;
                         }
@@ -237,13 +229,12 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
                         const float bt0 = bt;
                         const int bi0 = bi;
                         test_quads<SPH>(as_f4(f.a), as_f4(f.b), as_f4(f.c), o, d, bt, bi);
-                        for (uint32_t k = 1; k < cnt; ++k) test_record<SPH>(s.recs, first + k, o, d, bt, bi);
                         if (bt != bt0 || bi != bi0)
                             __hip_atomic_fetch_min(&slot[owner], ((unsigned long long)f2u(bt) << 32) | (uint32_t)bi, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
 #ifdef RTX_COUNT_STEPS
-                    st.leaves += cnt;
+                    ++st.leaves;
 #endif
                     cur = (sp == bot) ? kRefDone : st.get(--sp);
                 }

@@ -37,7 +37,7 @@
 //       sphere children are widened per ray at traversal time (kSphereK, rtx_traverse.h)
 // qlo is rounded down and qhi up, so a child's quantised box contains its padded box.
 // ref >= 0: index of another BvhNode; ref < 0: ~ref = (first << 3) | (count - 1),
-// a leaf of `count` (1..8) consecutive PrimRecs starting at `first`.
+// a leaf of `count` consecutive PrimRecs starting at `first`; count is always 1 (RTX_LEAF_MAX), the traversal reads `first` only.
 // ---------------------------------------------------------------------------
 struct PrimRec {
     float4 q0, q1, q2;
@@ -48,7 +48,7 @@ struct BvhNode {
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
-#define RTX_LEAF_MAX 1          // default primitives per leaf (tune3, 1..8): triangle fetches cost more than child boxes
+#define RTX_LEAF_MAX 1          // primitives per leaf: the fetch of a leaf reference IS its one record (leaves of 2-8 records behind a loop were slower)
 #define RTX_EXHAUSTIVE_MAX 16   // scenes with at most this many primitives skip the BVH
 #define RTX_TILE 8              // primary rays are generated in 8x8-pixel tiles (one wavefront)
 
@@ -94,7 +94,7 @@ struct DevScene {
     int* spill;                 // [spill_entries][spill_stride] overflow of the per-lane traversal stacks
     uint32_t spill_stride;      // thread slots = largest traversal grid * 256
     uint32_t spill_entries;
-    int32_t tune[4];            // traversal tuning: [0] busy lanes below which a wavefront shares work, [1] work units a wavefront should expect, in quarters (byte 0 closest hit, byte 1 shadow), [2] most workgroups per CU, [3] leaf size
+    int32_t tune[4];            // traversal tuning: [0] busy lanes below which a wavefront shares work, [1] work units a wavefront should expect, in quarters (byte 0 closest hit, byte 1 shadow), [2] most workgroups per CU, [3] unused
     unsigned long long* stamps; // diagnostics: [2 kinds][spill_stride / 64 wavefronts][4], or nullptr
 };
 

@@ -565,7 +565,18 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
     __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
-    if (sort_uo && blockIdx.x == 0) order_units(sort_uo);   // costs of the closest-hit launch just finished
+    // With costs to sort the launch has one workgroup more than the shading needs: the first one sorts the costs of the
+    // closest-hit launch just finished and does nothing else, so the sort (4-30 us for one to eight 1080p frames) runs
+    // beside the shading instead of in front of one workgroup's share of it.
+    uint32_t bid = blockIdx.x, nb = gridDim.x;
+    if (sort_uo) {
+        if (blockIdx.x == 0) {
+            order_units(sort_uo);
+            return;
+        }
+        --bid;
+        --nb;
+    }
     if (block_sees_overflow(ctl)) return;
     const uint32_t n = ctl->n_rays[qi];
     const uint32_t pool_base = ctl->pool_base;
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
     const uint32_t chunk = RTX_BLOCK * kShadeItems;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk) {   // block-uniform trip count
+    for (uint32_t c0 = bid * chunk; c0 < n; c0 += nb * chunk) {   // block-uniform trip count
         uint2 hit[kShadeItems];
         uint32_t pre[kShadeItems];
 #pragma unroll
@@ -874,19 +885,27 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(shadow_waves(ANY, AREA, S
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int qo, uint32_t node_depth, uint32_t n_samples,
                                                        OutMap out, int finalize, UnitOrder* sort_uo) {
     Ctl* ctl = wk.ctl;
-    if (sort_uo && blockIdx.x == 0) order_units(sort_uo);   // costs of the shadow launch just finished
+    uint32_t bid = blockIdx.x, nb = gridDim.x;
+    if (sort_uo) {   // the launch's first workgroup only sorts (costs of the shadow launch just finished), see k_shade_a
+        if (blockIdx.x == 0) {
+            order_units(sort_uo);
+            return;
+        }
+        --bid;
+        --nb;
+    }
     if (block_sees_overflow(ctl)) return;
     const uint32_t nn = ctl->n_nodes;
     const uint32_t pool_base = ctl->pool_base;   // node k of this level keeps slot pool_base + k of the pool (k_shade_a)
-    if (finalize && blockIdx.x == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
+    if (finalize && bid == 0 && threadIdx.x == 0) ctl->stat[ST_NODES] += min(nn, wk.cap_rays);
     const RayQueue q = wk.q[qo];
-    const uint32_t stride = gridDim.x * RTX_BLOCK;
+    const uint32_t stride = nb * RTX_BLOCK;
     const bool spawn = node_depth > 1;   // children are shaded at node_depth - 1
     __shared__ uint32_t s_wave_rays[RTX_BLOCK / 64], s_ray_base, s_stat[2];
     if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
     __syncthreads();
     uint32_t c_refl = 0, c_refr = 0;
-    for (uint32_t base = blockIdx.x * RTX_BLOCK; base < nn; base += stride) {
+    for (uint32_t base = bid * RTX_BLOCK; base < nn; base += stride) {
         const uint32_t node = base + threadIdx.x;
         bool refl = false, refr = false;
         V3 ro0, rd0, ro1, rd1;
@@ -1474,7 +1493,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             UnitOrder* uo1 = nullptr;
             launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, a, b);
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096) + (uo0 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
                                PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w, n_frames, (uint32_t)rays_per_frame}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = no_kt ? nullptr : ev.next(), d = no_kt ? nullptr : ev.next();
@@ -1484,7 +1503,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st, c, d);
                 shadow_events.emplace_back(c, d);
             }
-            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
+            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096) + (uo1 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
                                out_map, single_level ? 1 : 0, uo1);
             if (single_level) break;
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
