@@ -183,6 +183,8 @@ def host_lib():
         H.rst_last_error.restype = C.c_char_p
         H.rst_scene_parse.argtypes = [C.c_char_p]
         H.rst_scene_parse.restype = C.c_void_p
+        H.rst_scene_parse_objects.argtypes = [C.c_char_p]
+        H.rst_scene_parse_objects.restype = C.c_void_p
         H.rst_scene_desc.argtypes = [C.c_void_p]
         H.rst_scene_desc.restype = C.POINTER(SceneDesc)
         H.rst_scene_free.argtypes = [C.c_void_p]
@@ -285,10 +287,12 @@ class FlatScene:
         return f
 
 
-def parse_scene(path):
-    """SceneParser::new(path).parse_scene() (src/scene/parser/mod.rs:20,314) -> FlatScene, via librstracer.so."""
+def parse_scene(path, through_objects=False):
+    """SceneParser::new(path).parse_scene() (src/scene/parser/mod.rs:20,314) -> FlatScene, via librstracer.so:
+    one pass from the file to the arrays (SceneParser::parse_flat), or, with `through_objects`, through the
+    mirror of the reference's Scene / Poly / Vertex objects and flatten()."""
     H = host_lib()
-    h = H.rst_scene_parse(os.fsencode(path))
+    h = (H.rst_scene_parse_objects if through_objects else H.rst_scene_parse)(os.fsencode(path))
     if not h:
         raise RuntimeError("parse error: " + H.rst_last_error().decode())
     try:

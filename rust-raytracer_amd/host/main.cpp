@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     const std::string out = std::string(o ? o : "img") + ".bmp";                             // main.rs:67
     try {
         rstracer::SceneParser parser(scene_path);
-        rstracer::Scene scene = parser.parse_scene();
+        const rstracer::FlatScene scene = parser.parse_flat();   // file -> arrays in one pass (parse_scene + flatten give the same arrays)
         rstracer::RayTracer tracer = rstracer::RayTracer::init((uint32_t)width, (uint32_t)height, (size_t)depth, (size_t)samples);
         tracer.set_scene(std::make_unique<rstracer::GpuScene>(scene, (int)get_opt(g, 0), force_bvh));
         tracer.trace_rays().save(out);

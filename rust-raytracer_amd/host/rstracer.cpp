@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -314,6 +315,173 @@ static rtx_material to_rtx(const Material& m) {
     o.transparency = m.transparency;
     return o;
 }
+static rtx_light to_rtx(const Light& l) {
+    rtx_light o{};
+    o.type = (uint32_t)l.kind;
+    o.a[0] = l.pos.x; o.a[1] = l.pos.y; o.a[2] = l.pos.z;
+    o.b[0] = l.max.x; o.b[1] = l.max.y; o.b[2] = l.max.z;
+    o.color[0] = l.intensity.r; o.color[1] = l.intensity.g; o.color[2] = l.intensity.b;
+    return o;
+}
+static rtx_camera to_rtx(const Camera& c) {
+    rtx_camera o{};
+    o.pos[0] = c.pos.x; o.pos[1] = c.pos.y; o.pos[2] = c.pos.z;
+    o.view_dir[0] = c.view_dir.x; o.view_dir[1] = c.view_dir.y; o.view_dir[2] = c.view_dir.z;
+    o.ortho_up[0] = c.ortho_up.x; o.ortho_up[1] = c.ortho_up.y; o.ortho_up[2] = c.ortho_up.z;
+    o.focal_dist = c.focal_dist;
+    o.vertical_fov = c.vertical_fov;
+    return o;
+}
+Camera camera_of(const FlatScene& flat) {
+    const rtx_camera& c = flat.camera;
+    Camera o;
+    o.pos = Vec3{c.pos[0], c.pos[1], c.pos[2]};
+    o.view_dir = Vec3{c.view_dir[0], c.view_dir[1], c.view_dir[2]};
+    o.ortho_up = Vec3{c.ortho_up[0], c.ortho_up[1], c.ortho_up[2]};
+    o.focal_dist = c.focal_dist;
+    o.vertical_fov = c.vertical_fov;
+    return o;
+}
+std::vector<Light> lights_of(const FlatScene& flat) {
+    std::vector<Light> out;
+    for (const rtx_light& l : flat.lights) {
+        Light o;
+        o.kind = (Light::Kind)l.type;
+        o.pos = Vec3{l.a[0], l.a[1], l.a[2]};
+        o.max = Vec3{l.b[0], l.b[1], l.b[2]};
+        o.intensity.r = l.color[0]; o.intensity.g = l.color[1]; o.intensity.b = l.color[2];   // already clamped
+        out.push_back(o);
+    }
+    return out;
+}
+
+// ------------------------------------------------- file -> arrays, one pass ----
+// A poly_set (parser/mod.rs:236-298) straight into the triangle arrays. The set's polys enter the scene in
+// reverse file order (`polyset.pop()`, parser/mod.rs:333-338), so the set is appended in file order and its
+// range of the arrays is reversed at the end. A poly's material list (parser/mod.rs:266-291) is positional:
+// [vertex 0's material, vertex 1's if it differs, vertex 2's if it differs from both]; without per-vertex
+// binding it is [materials[0]]. The set's materials are appended to the table once, on first use.
+void SceneParser::flat_polyset(FlatScene& f, uint32_t& n_prims) {
+    expect("poly_set");
+    expect("{");
+    expect("name");
+    next_tok();
+    expect("numMaterials");
+    long nm = next_int();
+    std::vector<rtx_material> set_mats;
+    for (; nm > 0; --nm) set_mats.push_back(to_rtx(parse_material()));
+    std::vector<uint32_t> table(set_mats.size(), RTX_MATERIAL_NONE);   // index in the scene's material table, once used
+    auto mat = [&](uint32_t i) -> uint32_t {
+        if (i >= set_mats.size()) throw Error("index out of bounds: the len is " + std::to_string(set_mats.size()) + " but the index is " + std::to_string(i));
+        if (table[i] == RTX_MATERIAL_NONE) {
+            table[i] = (uint32_t)f.materials.size();
+            f.materials.push_back(set_mats[i]);
+        }
+        return table[i];
+    };
+    expect("type");
+    next_tok();
+    const bool vertex_normal = parse_bool("normType", "PER_VERTEX_NORMAL");
+    const bool vertex_material = parse_bool("materialBinding", "PER_VERTEX_MATERIAL");
+    expect("hasTextureCoords");
+    next_tok();
+    expect("rowSize");
+    next_tok();
+    expect("numPolys");
+    long np = next_int();
+    const size_t first = f.tri_flags.size();
+    if (np > 0) {
+        f.tri_pos.reserve(f.tri_pos.size() + (size_t)np * 9);
+        f.tri_normals.reserve(f.tri_normals.size() + (size_t)np * 9);
+        f.tri_mat.reserve(f.tri_mat.size() + (size_t)np * 3);
+        f.tri_flags.reserve(first + (size_t)np);
+    }
+    const uint8_t flags = (uint8_t)((vertex_normal ? RTX_TRI_VERTEX_NORMAL : 0) | (vertex_material ? RTX_TRI_VERTEX_MATERIAL : 0));
+    for (; np > 0; --np) {
+        expect("poly");                     // parse_poly, parser/mod.rs:216-234
+        expect("{");
+        expect("numVertices");
+        next_tok();                         // always 3
+        float pos[9], nrm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t mi[3] = {0, 0, 0};
+        for (int v = 0; v < 3; ++v) {       // parse_vertex, parser/mod.rs:195-214
+            expect("pos");
+            for (int k = 0; k < 3; ++k) pos[3 * v + k] = next_f32();
+            if (vertex_normal) {
+                expect("norm");
+                for (int k = 0; k < 3; ++k) nrm[3 * v + k] = next_f32();
+            }
+            if (vertex_material) {
+                expect("materialIndex");
+                mi[v] = (uint32_t)next_int();
+            }
+        }
+        expect("}");
+        uint32_t list[3] = {RTX_MATERIAL_NONE, RTX_MATERIAL_NONE, RTX_MATERIAL_NONE};
+        int n_list = 0;
+        if (vertex_material) {
+            list[n_list++] = mat(mi[0]);
+            if (mi[1] != mi[0]) list[n_list++] = mat(mi[1]);
+            if (mi[2] != mi[1] && mi[2] != mi[0]) list[n_list++] = mat(mi[2]);
+        } else {
+            list[n_list++] = mat(0);
+        }
+        f.tri_pos.insert(f.tri_pos.end(), pos, pos + 9);
+        f.tri_normals.insert(f.tri_normals.end(), nrm, nrm + 9);
+        f.tri_mat.insert(f.tri_mat.end(), list, list + 3);
+        f.tri_flags.push_back(flags);
+    }
+    expect("}");
+    const size_t count = f.tri_flags.size() - first;
+    for (size_t a = 0, b = count; a + 1 < b; ++a) {   // reverse the set's range
+        --b;
+        std::swap_ranges(f.tri_pos.begin() + (first + a) * 9, f.tri_pos.begin() + (first + a) * 9 + 9, f.tri_pos.begin() + (first + b) * 9);
+        std::swap_ranges(f.tri_normals.begin() + (first + a) * 9, f.tri_normals.begin() + (first + a) * 9 + 9, f.tri_normals.begin() + (first + b) * 9);
+        std::swap_ranges(f.tri_mat.begin() + (first + a) * 3, f.tri_mat.begin() + (first + a) * 3 + 3, f.tri_mat.begin() + (first + b) * 3);
+    }                                                 // (the flags of a set are all the same)
+    f.tri_prim_index.reserve(first + count);
+    for (size_t k = 0; k < count; ++k) f.tri_prim_index.push_back(n_prims++);
+}
+FlatScene SceneParser::parse_flat() {   // parse_scene (parser/mod.rs:314-346) emitting arrays
+    expect("Composer");
+    expect("format");
+    expect("2.1");
+    expect("ascii");
+    FlatScene f;
+    uint32_t n_prims = 0;
+    std::string tkn = peak();
+    while (has_next_token()) {
+        if (tkn == "camera") {
+            f.camera = to_rtx(parse_camera());
+        } else if (tkn == "sphere") {
+            const Sphere s = parse_sphere();
+            put3(f.sph_center_radius, s.origin);
+            f.sph_center_radius.push_back(s.radius);
+            if (!s.materials.empty()) {
+                const rtx_material m = to_rtx(s.materials[0]);
+                // spheres that follow each other with the same material share its entry
+                if (!f.sph_mat.empty() && f.sph_mat.back() != RTX_MATERIAL_NONE && std::memcmp(&f.materials[f.sph_mat.back()], &m, sizeof(m)) == 0) {
+                    f.sph_mat.push_back(f.sph_mat.back());
+                } else {
+                    f.sph_mat.push_back((uint32_t)f.materials.size());
+                    f.materials.push_back(m);
+                }
+            } else {
+                f.sph_mat.push_back(RTX_MATERIAL_NONE);
+            }
+            f.sph_prim_index.push_back(n_prims++);
+        } else if (tkn == "poly_set") {
+            flat_polyset(f, n_prims);
+        } else if (tkn.size() >= 5 && tkn.compare(tkn.size() - 5, 5, "light") == 0) {
+            f.lights.push_back(to_rtx(parse_light()));
+        } else {
+            throw Error("Unexpected token: " + tkn);
+        }
+        tkn = peak();
+    }
+    return f;
+}
+
 FlatScene flatten(const Scene& scene) {
     FlatScene f;
     for (size_t id = 0; id < scene.primitives.size(); ++id) {
@@ -345,20 +513,8 @@ FlatScene flatten(const Scene& scene) {
             f.sph_prim_index.push_back((uint32_t)id);
         }
     }
-    for (const Light& l : scene.lights) {
-        rtx_light o{};
-        o.type = (uint32_t)l.kind;
-        o.a[0] = l.pos.x; o.a[1] = l.pos.y; o.a[2] = l.pos.z;
-        o.b[0] = l.max.x; o.b[1] = l.max.y; o.b[2] = l.max.z;
-        o.color[0] = l.intensity.r; o.color[1] = l.intensity.g; o.color[2] = l.intensity.b;
-        f.lights.push_back(o);
-    }
-    const Camera& c = scene.camera;
-    f.camera.pos[0] = c.pos.x; f.camera.pos[1] = c.pos.y; f.camera.pos[2] = c.pos.z;
-    f.camera.view_dir[0] = c.view_dir.x; f.camera.view_dir[1] = c.view_dir.y; f.camera.view_dir[2] = c.view_dir.z;
-    f.camera.ortho_up[0] = c.ortho_up.x; f.camera.ortho_up[1] = c.ortho_up.y; f.camera.ortho_up[2] = c.ortho_up.z;
-    f.camera.focal_dist = c.focal_dist;
-    f.camera.vertical_fov = c.vertical_fov;
+    for (const Light& l : scene.lights) f.lights.push_back(to_rtx(l));
+    f.camera = to_rtx(scene.camera);
     return f;
 }
 rtx_scene_desc FlatScene::desc() const {
@@ -386,10 +542,15 @@ static void check(rtx_context* ctx, int rc, const char* what) {
     if (rc != RTX_OK) throw Error(std::string(what) + ": " + rtx_last_error(ctx));
 }
 GpuScene::GpuScene(const Scene& scene, int device, bool force_bvh) : camera_(scene.camera), lights_(scene.lights) {
+    upload(flatten(scene), device, force_bvh);
+}
+GpuScene::GpuScene(const FlatScene& flat, int device, bool force_bvh) : camera_(camera_of(flat)), lights_(lights_of(flat)) {
+    upload(flat, device, force_bvh);
+}
+void GpuScene::upload(const FlatScene& flat, int device, bool force_bvh) {
     int rc = rtx_create(device, &ctx_);
     if (rc != RTX_OK) throw Error(std::string("rtx_create: ") + rtx_last_error(nullptr));
     if (force_bvh) (void)rtx_set_option(ctx_, "force_mode", 2);
-    const FlatScene flat = flatten(scene);
     const rtx_scene_desc d = flat.desc();
     rc = rtx_scene_set(ctx_, &d);
     if (rc == RTX_OK) rc = rtx_build(ctx_, &build_);
@@ -507,6 +668,19 @@ rst_scene* rst_scene_parse(const char* path) {
     try {
         rstracer::SceneParser parser(path ? path : "");
         auto* s = new rst_scene();
+        s->flat = parser.parse_flat();
+        s->desc = s->flat.desc();
+        return s;
+    } catch (const std::exception& e) {
+        g_rst_error = e.what();
+        return nullptr;
+    }
+}
+/* The same scene through the object graph (SceneParser::parse_scene + flatten): what the tests hold parse_flat against. */
+rst_scene* rst_scene_parse_objects(const char* path) {
+    try {
+        rstracer::SceneParser parser(path ? path : "");
+        auto* s = new rst_scene();
         s->flat = rstracer::flatten(parser.parse_scene());
         s->desc = s->flat.desc();
         return s;
@@ -522,7 +696,7 @@ int rst_render_file(const char* scene_path, const char* out_bmp, uint32_t width,
                     uint32_t samples, int device) {
     try {
         rstracer::SceneParser parser(scene_path ? scene_path : "");
-        rstracer::Scene scene = parser.parse_scene();
+        const rstracer::FlatScene scene = parser.parse_flat();
         rstracer::RayTracer rt = rstracer::RayTracer::init(width, height, depth, samples);
         rt.set_scene(std::make_unique<rstracer::GpuScene>(scene, device));
         rt.trace_rays().save(out_bmp ? out_bmp : "img.bmp");

@@ -85,6 +85,8 @@ struct SceneIntersection {   // src/scene/mod.rs:143-146 + intersection.rs:7-11
     int32_t primitive = -1;   // index into Scene::primitives
 };
 
+struct FlatScene;
+
 // SceneParser (src/scene/parser/mod.rs:12-352). Strict keyword order; any
 // mismatch throws Error with the message the reference would panic with.
 class SceneParser {
@@ -92,6 +94,11 @@ public:
     explicit SceneParser(const std::string& path);   // SceneParser::new
     ~SceneParser();
     Scene parse_scene();
+    // The same grammar, errors and primitive numbering in ONE pass from the file to the flattened arrays, without
+    // the object graph in between (parse_scene holds three Vertex objects and a std::vector<Material> per triangle:
+    // several hundred bytes and a heap allocation each, which is what a scene of millions of triangles cannot
+    // afford). A poly_set's materials enter the material table once instead of once per triangle.
+    FlatScene parse_flat();
     // pieces exposed for the parser tests (parser/test/mod.rs)
     std::string next_token();
     std::string peak();
@@ -114,6 +121,7 @@ private:
     float parse_f32(const char* name);
     bool parse_bool(const char* name, const char* flag);
     Vertex parse_vertex(bool has_normal, bool has_material);
+    void flat_polyset(FlatScene& f, uint32_t& n_prims);
     const char* data_ = nullptr;
     size_t size_ = 0, pos_ = 0;
     bool mapped_ = false, finished_ = false, peaked_ = false;
@@ -131,6 +139,8 @@ struct FlatScene {
     rtx_scene_desc desc() const;
 };
 FlatScene flatten(const Scene& scene);
+Camera camera_of(const FlatScene& flat);
+std::vector<Light> lights_of(const FlatScene& flat);
 
 // The drop-in implementation of IntersectableScene (src/scene/mod.rs:148-154):
 // owns an rtx_context with the scene uploaded and built.
@@ -139,6 +149,7 @@ public:
     // force_bvh: what the reference's `-b` flag selects (BvhScene instead of Scene, src/main.rs:70-74). Here the tree is
     // then built even for the few-primitive scenes the library would otherwise sweep exhaustively; results are the same.
     explicit GpuScene(const Scene& scene, int device = 0, bool force_bvh = false);
+    explicit GpuScene(const FlatScene& flat, int device = 0, bool force_bvh = false);   // a scene read with parse_flat
     ~GpuScene();
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
@@ -150,6 +161,7 @@ public:
     const rtx_build_stats& build_stats() const { return build_; }
 
 private:
+    void upload(const FlatScene& flat, int device, bool force_bvh);
     rtx_context* ctx_ = nullptr;
     Camera camera_;
     std::vector<Light> lights_;

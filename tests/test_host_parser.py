@@ -36,6 +36,93 @@ def test_product_parser_equals_oracle_parser(name, rtx, orc):
     assert bytes(a.camera) == bytes(b.camera)
 
 
+@pytest.mark.parametrize("name", BUNDLED + ["area"])
+def test_one_pass_parser_equals_the_object_path(name, rtx):
+    """SceneParser::parse_flat (file -> arrays) against parse_scene + flatten (the mirror of the reference's objects)."""
+    a = rtx.parse_scene(scene_path(name))
+    b = rtx.parse_scene(scene_path(name), through_objects=True)
+    assert (a.n_tris, a.n_spheres) == (b.n_tris, b.n_spheres)
+    assert resolved(a, a.materials) == resolved(b, b.materials)
+    assert np.array_equal(a.tri_prim_index, b.tri_prim_index) and np.array_equal(a.sph_prim_index, b.sph_prim_index)
+    assert a.lights.tobytes() == b.lights.tobytes() and bytes(a.camera) == bytes(b.camera)
+    assert len(a.materials) <= len(b.materials)      # a set's materials enter the table once, not once per triangle
+
+
+MALFORMED = [
+    "Composer format 2.1 ascii\ncamera {\n  position 0 0 zero\n}\n",
+    "Composer format 2.1 ascii\nteapot {\n}\n",
+    "Composer format 2.0 ascii\n",
+    "Composer format 2.1 ascii\npoint_light {\n position 0 0 0\n colour 1 1 1\n}\n",
+    # a material index past the set's list (the reference panics on the slice index while it builds the poly)
+    "Composer format 2.1 ascii\npoly_set {\n name x\n numMaterials 1\n material {\n diffColor 1 1 1\n ambColor 0 0 0\n specColor 0 0 0\n"
+    " emisColor 0 0 0\n shininess 0\n ktran 0\n }\n type POLYSET_TRI_MESH\n normType PER_FACE_NORMAL\n materialBinding PER_VERTEX_MATERIAL\n"
+    " hasTextureCoords FALSE\n rowSize 0\n numPolys 1\n poly {\n numVertices 3\n pos 0 0 0\n materialIndex 0\n pos 1 0 0\n materialIndex 3\n"
+    " pos 0 1 0\n materialIndex 0\n }\n}\n",
+    # a set without materials
+    "Composer format 2.1 ascii\npoly_set {\n name x\n numMaterials 0\n type POLYSET_TRI_MESH\n normType PER_FACE_NORMAL\n"
+    " materialBinding PER_OBJECT_MATERIAL\n hasTextureCoords FALSE\n rowSize 0\n numPolys 1\n poly {\n numVertices 3\n pos 0 0 0\n pos 1 0 0\n"
+    " pos 0 1 0\n }\n}\n",
+    # truncated in the middle of a poly
+    "Composer format 2.1 ascii\npoly_set {\n name x\n numMaterials 0\n type POLYSET_TRI_MESH\n normType PER_FACE_NORMAL\n"
+    " materialBinding PER_OBJECT_MATERIAL\n hasTextureCoords FALSE\n rowSize 0\n numPolys 2\n poly {\n numVertices 3\n pos 0 0 0\n pos 1 0",
+]
+
+
+@pytest.mark.parametrize("k", range(len(MALFORMED)))
+def test_both_parser_paths_fail_with_the_same_message(k, rtx, tmp_path):
+    bad = tmp_path / "bad.ascii"
+    bad.write_text(MALFORMED[k])
+    with pytest.raises(RuntimeError) as e1:
+        rtx.parse_scene(str(bad))
+    with pytest.raises(RuntimeError) as e2:
+        rtx.parse_scene(str(bad), through_objects=True)
+    assert str(e1.value) == str(e2.value)
+
+
+def test_one_pass_parser_on_a_large_mesh(rtx, tmp_path):
+    """A 200 000-triangle height field written out as .ascii with per-vertex normals and three materials bound per
+    vertex: both paths give the same scene, and the one-pass path keeps the material table at the set's three entries."""
+    import time
+    n = 316
+    xs = np.linspace(-1.0, 1.0, n + 1, dtype=np.float32)
+    path = tmp_path / "mesh.ascii"
+    with open(path, "w") as f:
+        f.write("Composer format 2.1 ascii\ncamera {\n position 0 1 2\n viewDirection 0 -0.4 -1\n focalDistance 1\n orthoUp 0 1 0\n verticalFOV 0.6\n}\n")
+        f.write("point_light {\n position 1 2 1\n color 1 1 1\n}\n")
+        f.write("poly_set {\n name mesh\n numMaterials 3\n")
+        for c in ("1 0 0", "0 1 0", "0 0 1"):
+            f.write(" material {\n diffColor %s\n ambColor 0.2 0.2 0.2\n specColor 0 0 0\n emisColor 0 0 0\n shininess 0.2\n ktran 0\n }\n" % c)
+        f.write(" type POLYSET_TRI_MESH\n normType PER_VERTEX_NORMAL\n materialBinding PER_VERTEX_MATERIAL\n hasTextureCoords FALSE\n rowSize 0\n")
+        f.write(" numPolys %d\n" % (2 * n * n))
+        rows = []
+        for i in range(n):
+            for j in range(n):
+                q = [(xs[j], 0.05 * ((i * 7 + j * 3) % 5), xs[i]), (xs[j + 1], 0.0, xs[i]), (xs[j], 0.0, xs[i + 1]), (xs[j + 1], 0.03, xs[i + 1])]
+                for tri in ((0, 1, 2), (2, 1, 3)):
+                    rows.append(" poly {\n numVertices 3\n" + "".join(
+                        "  pos %r %r %r\n  norm 0 1 0\n  materialIndex %d\n" % (float(q[v][0]), float(q[v][1]), float(q[v][2]), (i + j + v) % 3)
+                        for v in tri) + " }\n")
+        f.write("".join(rows))
+        f.write("}\n")
+    size_mb = os.path.getsize(path) / 1e6
+    t0 = time.perf_counter()
+    a = rtx.parse_scene(str(path))
+    t1 = time.perf_counter()
+    b = rtx.parse_scene(str(path), through_objects=True)
+    t2 = time.perf_counter()
+    print("one pass %.0f MB/s, through objects %.0f MB/s (%.0f MB)" % (size_mb / (t1 - t0), size_mb / (t2 - t1), size_mb))
+    assert a.n_tris == b.n_tris == 2 * n * n
+    assert len(a.materials) == 3 and len(b.materials) > a.n_tris
+    assert np.array_equal(a.tri_pos, b.tri_pos) and np.array_equal(a.tri_normals, b.tri_normals) and np.array_equal(a.tri_flags, b.tri_flags)
+    assert np.array_equal(a.tri_prim_index, b.tri_prim_index)
+    ma, mb = a.materials.view(np.uint8).reshape(len(a.materials), -1), b.materials.view(np.uint8).reshape(len(b.materials), -1)
+    for k in range(3):
+        ia, ib = a.tri_mat[:, k], b.tri_mat[:, k]
+        assert np.array_equal(ia == 0xFFFFFFFF, ib == 0xFFFFFFFF)
+        sel = ia != 0xFFFFFFFF
+        assert np.array_equal(ma[ia[sel]], mb[ib[sel]])
+
+
 def test_parser_errors_are_reported_not_fatal(rtx, tmp_path):
     bad = tmp_path / "bad.ascii"
     bad.write_text("Composer format 2.1 ascii\ncamera {\n  position 0 0 zero\n}\n")
