@@ -53,6 +53,9 @@ struct Work {
     // Hits per chunk of 2048 rays (counted by the closest-hit kernel) and their exclusive prefix
     // (k_scan_chunks): node slots follow ray order, whatever order the workgroups run in.
     uint32_t *chunk_cnt, *chunk_base;
+    // per work unit (64 rays) of the closest-hit launch: which of its rays hit something. Rays that missed write no hit
+    // record and k_shade_a reads none for them (in the 1080p bench frame 78 % of the primary rays leave the scene).
+    unsigned long long* hit_mask;
     uint32_t cap_pool;
     uint32_t n_samples;          // RayTracer::num_samples, at least 1 here
     uint32_t area_off;           // num_samples == 0: area lights trace nothing and contribute nothing
@@ -420,7 +423,8 @@ static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_sh
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
 template <bool SPH, bool ALWAYS = false>
-__global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt) {
+__global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt,
+                                                                                                                    unsigned long long* hit_mask) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
     __shared__ CoopLds coop;
     constexpr uint32_t kTop = top_nodes(closest_waves(SPH));
@@ -458,8 +462,13 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void 
         float t = 0.0f;
         coop_trace<false, SPH, ALWAYS>(s, tc, (f2u(d4.w) & RTX_RAY_VALID) != 0, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 0.0f, st, coop,
                           s.tune[0], t, id);
-        if (i < n) q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
         const uint64_t hits = __ballot(i < n && id >= 0);
+        if (hit_mask) {   // the reader goes by the unit's mask: only hits are stored
+            if (i < n && id >= 0) q.hit[i] = make_uint2((uint32_t)id, f2u(t));
+            if ((threadIdx.x & 63) == 0) hit_mask[unit] = hits;
+        } else if (i < n) {
+            q.hit[i] = make_uint2((uint32_t)id, f2u(id >= 0 ? t : 0.0f));
+        }
         if (chunk_cnt && hits && (threadIdx.x & 63) == 0) atomicAdd(&chunk_cnt[unit >> kChunkUnitsLog2], (uint32_t)__popcll(hits));
         uq.record(unit, unit_start);
 #ifdef RTX_COUNT_STEPS
@@ -531,26 +540,77 @@ RTX_D void store_pixel(const OutMap& out, uint32_t link, Col c) {   // Color::as
 // the chunk slots follow the ray order, so the node order is the ray order: no atomics, and
 // the same frame gives the same order every time.
 
-// Exclusive prefix of the per-chunk hit counts (one workgroup of 1024 threads: a batch of 16 Mi rays has 16 Ki chunks,
-// and a thread's chunks are read one dependent access after the other, so the kernel is as long as its longest thread);
-// sets the level's node count and clears the counts for the next launch.
+// Exclusive prefix of the per-chunk hit counts (one workgroup of 1024 threads: a batch of 16 Mi rays has 16 Ki chunks);
+// sets the level's node count and clears the counts for the next launch. One CU does all of it, so what counts is how
+// many cache lines its accesses touch: thread t takes the chunks t, t + 1024, ... (a wavefront reads and writes whole
+// lines; a thread walking 16 consecutive chunks made every access of a wavefront 64 lines wide, 21 us for 16 Ki
+// chunks), rows of 1024 chunks are scanned inside the wavefronts with shuffles, and the 16 x 16 (row, wavefront)
+// totals are scanned once by the first wavefront.
 constexpr int kScanThreads = 1024;
 __global__ __launch_bounds__(kScanThreads) void k_scan_chunks(Ctl* ctl, int qi, uint32_t* __restrict__ cnt, uint32_t* __restrict__ base) {
-    __shared__ uint32_t wave_sum[kScanThreads / 64];
+    constexpr uint32_t kRows = 16, kWaves = kScanThreads / 64;
+    __shared__ uint32_t tot[kRows * kWaves];
+    __shared__ uint32_t wave_sum[kWaves];
     const uint32_t n_chunks = (ctl->n_rays[qi] + RTX_BLOCK * kShadeItems - 1) / (RTX_BLOCK * kShadeItems);
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (n_chunks <= kRows * kScanThreads) {   // block-uniform
+        uint32_t v[kRows], inc[kRows];
+#pragma unroll
+        for (uint32_t j = 0; j < kRows; ++j) {
+            const uint32_t c = j * kScanThreads + t;
+            v[j] = (c < n_chunks) ? cnt[c] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRows; ++j) {
+            uint32_t x = v[j];
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o);
+                if ((int)lane >= o) x += y;
+            }
+            inc[j] = x;
+            if (lane == 63) tot[j * kWaves + wave] = x;
+        }
+        __syncthreads();
+        if (wave == 0) {   // the 256 totals in (row, wavefront) order = chunk order: four per lane
+            const uint32_t a0 = tot[4 * lane], a1 = tot[4 * lane + 1], a2 = tot[4 * lane + 2], a3 = tot[4 * lane + 3];
+            const uint32_t sum = a0 + a1 + a2 + a3;
+            uint32_t x = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o);
+                if ((int)lane >= o) x += y;
+            }
+            const uint32_t ex = x - sum;
+            tot[4 * lane] = ex;
+            tot[4 * lane + 1] = ex + a0;
+            tot[4 * lane + 2] = ex + a0 + a1;
+            tot[4 * lane + 3] = ex + a0 + a1 + a2;
+            if (lane == 63) ctl->n_nodes = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < kRows; ++j) {
+            const uint32_t c = j * kScanThreads + t;
+            if (c < n_chunks) {
+                base[c] = tot[j * kWaves + wave] + inc[j] - v[j];
+                cnt[c] = 0;
+            }
+        }
+        return;
+    }
+    // larger batches ("batch_pixels" above the default): a thread walks its consecutive chunks
     const uint32_t per = (n_chunks + kScanThreads - 1) / kScanThreads;
-    const uint32_t t = threadIdx.x, lo = min(t * per, n_chunks), hi = min(lo + per, n_chunks);
+    const uint32_t lo = min(t * per, n_chunks), hi = min(lo + per, n_chunks);
     uint32_t sum = 0;
     for (uint32_t c = lo; c < hi; ++c) sum += cnt[c];
     uint32_t incl = sum;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(incl, o);
-        if ((int)(t & 63) >= o) incl += v;
+        if ((int)lane >= o) incl += v;
     }
-    if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+    if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
     uint32_t run = incl - sum;
-    for (uint32_t w = 0; w < (t >> 6); ++w) run += wave_sum[w];
+    for (uint32_t w = 0; w < wave; ++w) run += wave_sum[w];
     for (uint32_t c = lo; c < hi; ++c) {
         base[c] = run;
         run += cnt[c];
@@ -590,7 +650,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
 #pragma unroll
         for (int k = 0; k < kShadeItems; ++k) {
             const uint32_t i = c0 + k * RTX_BLOCK + threadIdx.x;
-            hit[k] = (i < n) ? q.hit[i] : make_uint2(0xffffffffu, 0u);
+            hit[k] = make_uint2(0xffffffffu, 0u);
+            if ((i & ~63u) < n && ((wk.hit_mask[i >> 6] >> lane) & 1ull)) hit[k] = q.hit[i];   // i's unit = this wavefront's 64 rays
             const uint64_t m = __ballot((int)hit[k].x >= 0);
             pre[k] = (uint32_t)__popcll(m & lt);
             if (lane == 0) cnt[k][w] = (uint32_t)__popcll(m);
@@ -1121,6 +1182,7 @@ int ensure_workspace(rtx_context* ctx, uint64_t batch, uint32_t slots, Work* out
         const size_t chunks = (size_t)wk.cap_rays / (RTX_BLOCK * kShadeItems) + 2;
         W_TRY(walloc(ctx, &wk.chunk_cnt, chunks));
         W_TRY(walloc(ctx, &wk.chunk_base, chunks));
+        W_TRY(walloc(ctx, &wk.hit_mask, (size_t)wk.cap_rays / 64 + 2));
         if (hipMemsetAsync(wk.chunk_cnt, 0, chunks * sizeof(uint32_t), ctx->stream) != hipSuccess)
             return rtx_fail(ctx, RTX_ERR_HIP, "hipMemsetAsync(chunk counts) failed");
     }
@@ -1236,15 +1298,16 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(ctx->ds)))), block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
+    unsigned long long* masks = shade ? wk.hit_mask : nullptr;
     if (ctx->ds.n_always) {
-        if (t0 || t1) hipExtLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
-        else hipLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        if (t0 || t1) hipExtLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        else hipLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
     } else if (ctx->ds.n_spheres) {
-        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
-        else hipLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        else hipLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
     } else {
-        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
-        else hipLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts);
+        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        else hipLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
     }
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kScanThreads), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
