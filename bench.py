@@ -265,8 +265,8 @@ def main():
     # Frames per batch: a rank's 1/N share of one small frame cannot fill a GPU (its launches are as long as their
     # longest ray chains however few rays they hold), so sharded runs render the shares of several frames at once.
     # Larger launches also lose less at their ends (a launch finishes with its slowest wavefronts while the rest of the
-    # GPU idles), so the 1080p configuration renders 8 frames per batch and GPU (the library's limit is 32 frames per batch,
-    # which caps 8 ranks at 4 frames each) -- measured 8.9 / 10.5 / 13.4 / 14.3 Grays/s with 1 / 2 / 4 / 8 frames per
+    # GPU idles), so the 1080p configuration renders 8 frames per batch and GPU (64 frames per batch, the library's limit,
+    # on 8 ranks) -- measured 8.9 / 10.5 / 13.4 / 14.3 Grays/s with 1 / 2 / 4 / 8 frames per
     # batch on one GPU. The 4K and 8K configurations render frame by frame.
     if args.frames_per_batch > 0:
         fpb = args.frames_per_batch

@@ -284,7 +284,7 @@ int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, 
  * All frames' rays must fit one ray batch (the "batch_pixels" option, default 16 Mi rays): RTX_ERR_INVALID_ARG
  * otherwise. The _async form enqueues and returns like rtx_render_tiles_async; rtx_render_wait collects the batch
  * (ray counts are totals over its frames). */
-#define RTX_MAX_BATCH_FRAMES 32u
+#define RTX_MAX_BATCH_FRAMES 64u
 int rtx_render_frames(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width, uint32_t height,
                       uint32_t depth, uint32_t samples, uint32_t rank, uint32_t world, uint8_t* d_out, int row_major,
                       rtx_render_stats* stats);

@@ -22,7 +22,7 @@ pub const RTX_TRI_VERTEX_NORMAL: u8 = 1;
 pub const RTX_TRI_VERTEX_MATERIAL: u8 = 2;
 pub const RTX_NOALLOC_MAX_RAYS: u64 = 1 << 26;
 pub const RTX_COMM_ID_BYTES: usize = 128;
-pub const RTX_MAX_BATCH_FRAMES: u32 = 32;
+pub const RTX_MAX_BATCH_FRAMES: u32 = 64;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

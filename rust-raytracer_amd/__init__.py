@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "rtx_comm_unique_id", "rtx_comm_init", "rtx_comm_destroy", "rtx_scene_broadcast", "rtx_gather_frame",
     "rtx_render_frames", "rtx_render_frames_async", "rtx_assemble_frames_async", "rtx_gather_frames",
 ]
-MAX_BATCH_FRAMES = 32
+MAX_BATCH_FRAMES = 64
 
 
 class RtxError(RuntimeError):

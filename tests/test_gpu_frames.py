@@ -215,9 +215,9 @@ def test_batch_limits(rtx, gpu_ctx_factory):
     torch = pytest.importorskip("torch")
     flat = rtx.parse_scene(scene_path("test04"))
     ctx = gpu_ctx_factory(flat)
-    buf = torch.zeros(33 * 64 * 64 * 3, dtype=torch.uint8, device="cuda:0")
+    buf = torch.zeros((rtx.MAX_BATCH_FRAMES + 1) * 64 * 64 * 3, dtype=torch.uint8, device="cuda:0")
     with pytest.raises(rtx.RtxError) as e:
-        ctx.render_frames(33, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)     # more than RTX_MAX_BATCH_FRAMES
+        ctx.render_frames(rtx.MAX_BATCH_FRAMES + 1, None, 64, 64, 5, 1, 0, 1, buf.data_ptr(), True)     # more than RTX_MAX_BATCH_FRAMES
     assert e.value.status == 1
     with pytest.raises(rtx.RtxError) as e:
         ctx.render_frames(2, None, 64, 64, 5, 1, 0, 2, buf.data_ptr(), True)      # row-major output with two ranks
