@@ -6,9 +6,9 @@ Workload (BASELINE.json configs[2], the largest single-GPU configuration): synth
 (the reference's default; the scene has no reflective or refractive material, so one
 level of rays is traced: primary + 4 shadow rays per hit). One step = one batch of
 --frames-per-step frames of that view (default 100 for this workload, so that the timed region
-of a 20-step run is about a second, not ten milliseconds), scene and BVH resident in HBM;
-frames are pipelined (the next frame is enqueued while the last one is collected) and all of
-them are complete before the clock stops. N > 1: the frame is sharded by interleaved 8x8 tiles,
+of a 20-step run is about a second, not ten milliseconds), rendered eight per GPU and set of
+launches (--frames-per-batch), scene and BVH resident in HBM; batches are pipelined (the next
+one is enqueued while the last one is collected) and all of them are complete before the clock stops. N > 1: the frame is sharded by interleaved 8x8 tiles,
 the scene is broadcast once from rank 0 over RCCL and every frame's tile slabs are all-gathered
 and assembled (strong scaling: the frame is fixed).
 
