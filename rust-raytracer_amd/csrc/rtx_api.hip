@@ -282,6 +282,19 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
         lights[i] = l;
     }
     S_TRY(upload(ctx, *store, lights.data(), lights.size(), &d_lights));
+    s.prim_ref = d_ref;
+    s.tri_pos = d_pos;
+    s.tri_nrm = d_nrm;
+    s.tri_mat = d_tmat;
+    s.tri_flags = d_flags;
+    s.sph = d_sph;
+    s.sph_mat = d_smat;
+    s.mats = d_mats;
+    s.lights = d_lights;
+    uint4* d_srec = nullptr;
+    S_TRY(upload(ctx, *store, (const uint4*)nullptr, (size_t)n * 4, &d_srec));
+    S_TRY(rtx_build_shade_recs(ctx, s, d_srec));
+    s.shade_recs = d_srec;
 #undef S_TRY
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope below
 
@@ -303,15 +316,6 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
         const float sc = std::sqrt(m.specular[0] * m.specular[0] + m.specular[1] * m.specular[1] + m.specular[2] * m.specular[2]);
         if (sc > 0.0f || m.transparency > 0.0f || sc != sc || m.transparency != m.transparency) ctx->has_secondary = true;
     }
-    s.prim_ref = d_ref;
-    s.tri_pos = d_pos;
-    s.tri_nrm = d_nrm;
-    s.tri_mat = d_tmat;
-    s.tri_flags = d_flags;
-    s.sph = d_sph;
-    s.sph_mat = d_smat;
-    s.mats = d_mats;
-    s.lights = d_lights;
     for (int i = 0; i < 4; ++i) s.tune[i] = ctx->opt_tune[i];
     ctx->ds = s;
     ctx->camera = d->camera;

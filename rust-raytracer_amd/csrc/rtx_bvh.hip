@@ -738,6 +738,29 @@ __global__ __launch_bounds__(kThreads) void k_prim_ref(uint32_t n_tris, uint32_t
     if (__ballot(normals) && (threadIdx.x & 63) == 0) atomicOr(&status[1], 1u);
 }
 
+// DevScene::shade_recs from the scene's arrays (one thread per reference primitive id).
+__global__ __launch_bounds__(kThreads) void k_shade_recs(DevScene s, uint4* __restrict__ out) {
+    for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < s.n_prims; id += gridDim.x * kThreads) {
+        const uint32_t ref = s.prim_ref[id];
+        const uint32_t idx = ref & 0x7fffffffu;
+        uint4 a, b, c = make_uint4(0u, 0u, 0u, 0u), d = make_uint4(0u, 0u, 0u, 0u);
+        if (ref >> 31) {
+            const float4 sp = s.sph[idx];
+            a = make_uint4(__float_as_uint(sp.x), __float_as_uint(sp.y), __float_as_uint(sp.z), ref);
+            b = make_uint4(__float_as_uint(sp.w), 0u, 0u, s.sph_mat[idx]);
+        } else {
+            const float* p = s.tri_pos + (size_t)idx * 9;
+            const uint32_t* m = s.tri_mat + (size_t)idx * 3;
+            a = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), idx | ((uint32_t)(s.tri_flags[idx] & 3u) << 28));
+            b = make_uint4(__float_as_uint(p[3]), __float_as_uint(p[4]), __float_as_uint(p[5]), m[0]);
+            c = make_uint4(__float_as_uint(p[6]), __float_as_uint(p[7]), __float_as_uint(p[8]), m[1]);
+            d.x = m[2];
+        }
+        uint4* o = out + (size_t)id * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+    }
+}
+
 template <typename T>
 int dev_alloc(rtx_context* ctx, std::vector<void*>& owner, T** out, size_t count) {
     void* p = nullptr;
@@ -771,6 +794,13 @@ inline uint32_t grid_for(uint64_t n, uint32_t cap = 4096) {
 }
 
 }  // namespace
+
+int rtx_build_shade_recs(rtx_context* ctx, const DevScene& s, uint4* d_recs) {
+    static_assert((RTX_TRI_VERTEX_NORMAL | RTX_TRI_VERTEX_MATERIAL) == 3, "the record keeps two flag bits");
+    if (s.n_prims > 0) hipLaunchKernelGGL(k_shade_recs, dim3(grid_for(s.n_prims)), dim3(kThreads), 0, ctx->stream, s, d_recs);
+    RTX_HIP(ctx, hipGetLastError());
+    return RTX_OK;
+}
 
 int rtx_build_prim_ref(rtx_context* ctx, uint32_t n_tris, uint32_t n_spheres, const uint32_t* d_tri_index, const uint32_t* d_sph_index,
                        const uint8_t* d_tri_flags, uint32_t* d_ref, uint32_t* d_status) {

@@ -77,6 +77,11 @@ struct DevScene {
     const float4* sph;          // [n_spheres] (c.xyz, r)
     const uint32_t* sph_mat;    // [n_spheres]
     const rtx_material* mats;   // [n_materials]
+    // What shading a hit reads first, gathered into ONE aligned 64-byte record per reference primitive id (one cache
+    // line per hit instead of one each from prim_ref, tri_pos, tri_flags and tri_mat):
+    //   triangle: (p0, ref) (p1, mat 0) (p2, mat 1) (mat 2, -, -, -)   sphere: (centre, ref) (radius, -, -, mat)
+    //   ref = the prim_ref word with the triangle's flags in bits 28-29 (fewer than 2^28 primitives exist)
+    const uint4* shade_recs;    // [n_prims][4]
     const DevLight* lights;     // [n_lights]
     // traversal-side arrays
     const PrimRec* recs;        // [n_prims]
@@ -218,6 +223,7 @@ int rtx_fail(rtx_context* ctx, int status, const std::string& msg);
 // rtx_bvh.hip
 int rtx_bvh_build(rtx_context* ctx);
 int rtx_alloc_traversal_scratch(rtx_context* ctx);   // this context's stack overflow area (and stamps) for the built tree
+int rtx_build_shade_recs(rtx_context* ctx, const DevScene& s, uint4* d_recs);   // s: counts and shading arrays set
 int rtx_build_prim_ref(rtx_context* ctx, uint32_t n_tris, uint32_t n_spheres, const uint32_t* d_tri_index, const uint32_t* d_sph_index,
                        const uint8_t* d_tri_flags, uint32_t* d_ref, uint32_t* d_status /*[2]: bad permutation, some vertex normal*/);
 // rtx_trace.hip

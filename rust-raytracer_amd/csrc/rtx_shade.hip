@@ -623,7 +623,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_chunks(Ctl* ctl, int qi, 
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int qi, PixMap pm, PrimaryGen pg, OutMap out,
                                                        UnitOrder* sort_uo) {
     __shared__ uint32_t cnt[kShadeItems][RTX_BLOCK / 64];
-    __shared__ uint32_t s_base;
     Ctl* ctl = wk.ctl;
     // With costs to sort the launch has one workgroup more than the shading needs: the first one sorts the costs of the
     // closest-hit launch just finished and does nothing else, so the sort (4-30 us for one to eight 1080p frames) runs
@@ -645,6 +644,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
     for (uint32_t c0 = bid * chunk; c0 < n; c0 += nb * chunk) {   // block-uniform trip count
+        // slots of this chunk's hits: prefix of the chunks before it (one address for the workgroup, asked for before
+        // the hit records so that the two waits overlap)
+        const uint32_t chunk_first = wk.chunk_base[c0 / chunk];
         uint2 hit[kShadeItems];
         uint32_t pre[kShadeItems];
 #pragma unroll
@@ -657,9 +659,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             if (lane == 0) cnt[k][w] = (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_base = wk.chunk_base[c0 / chunk];   // slots of this chunk's hits: prefix of the chunks before it
-        __syncthreads();
-        uint32_t run = s_base;
+        uint32_t run = chunk_first;
         bool panic = false;
 #pragma unroll
         for (int k = 0; k < kShadeItems; ++k) {
@@ -994,6 +994,17 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
             const Col ambient_light = col_mult(cd * ka, 1.0f - kt);   // lib.rs:143-145
             Col direct_light = col_new();
             const uint64_t key = wk.pKey ? wk.pKey[slot] : 0ull;
+            // Without area lights slot j is light j and every slot was written (0 for a light that is skipped): the terms
+            // of up to four lights are asked for here, together, instead of one wait per light inside the loop.
+            const bool early_terms = s.n_area_lights == 0 && s.n_lights <= 4;   // uniform
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            if (early_terms) {
+                const float* term = wk.shadow + node;
+                if (s.n_lights > 0) t0 = term[0];
+                if (s.n_lights > 1) t1 = term[(size_t)wk.cap_rays];
+                if (s.n_lights > 2) t2 = term[(size_t)2 * wk.cap_rays];
+                if (s.n_lights > 3) t3 = term[(size_t)3 * wk.cap_rays];
+            }
             for (uint32_t j = 0; j < s.n_lights; ++j) {              // lib.rs:216-228, scene order
                 const DevLight light = s.lights[j];
                 const bool area = light.type == RTX_LIGHT_AREA;
@@ -1003,7 +1014,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
                     const uint32_t n = area ? n_samples : 1u;         // lib.rs:219-222
                     const float* term = wk.shadow + (size_t)first_slot(light, j, wk.n_samples) * wk.cap_rays + node;
                     float shade = 0.0f;                               // lib.rs:112-138
-                    for (uint32_t smp = 0; smp < n; ++smp) shade += term[(size_t)smp * wk.cap_rays];
+                    if (early_terms) shade += (j == 0) ? t0 : (j == 1) ? t1 : (j == 2) ? t2 : t3;
+                    else for (uint32_t smp = 0; smp < n; ++smp) shade += term[(size_t)smp * wk.cap_rays];
                     shade = clamp01(n != 1u ? shade / (float)n : shade);
                     direct_light = direct_light + direct_lightning(light, point, normal, dir, cd, ks, kt, shininess,
                                                                    Col{shade, shade, shade}, fattj, n, area ? rng_push(kl, 2) : 0ull);

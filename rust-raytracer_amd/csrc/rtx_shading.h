@@ -37,22 +37,25 @@ RTX_D HitGeom hit_geometry(const DevScene& s, int prim_id, V3 o, V3 d, float t, 
     g.blended = false;
     g.p = o + vmult(d, t);
     g.cd = col_new();
-    const uint32_t ref = s.prim_ref[prim_id];
-    const uint32_t idx = ref & 0x7fffffffu;
+    const uint4* rec = s.shade_recs + (size_t)prim_id * 4;   // one aligned 64-byte record per primitive (DevScene::shade_recs)
+    const uint4 ra = rec[0], rb = rec[1];
+    const uint32_t ref = ra.w;
     if (ref >> 31) {  // sphere
-        const float4 sp = s.sph[idx];
-        g.n = vnormalize(g.p - v3(sp.x, sp.y, sp.z));  // sphere.rs:109-113 (never flipped)
-        g.mat0 = s.sph_mat[idx];
+        g.n = vnormalize(g.p - v3(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z)));  // sphere.rs:109-113 (never flipped)
+        g.mat0 = rb.w;
         if (want_color) {
             const rtx_material* m = material_or_null(s, g.mat0);
             if (m) g.cd = col_raw(m->diffuse); else g.panic = true;
         }
         return g;
     }
-    const float* tp = s.tri_pos + (size_t)idx * 9;
-    const V3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
-    const uint32_t flags = s.tri_flags[idx];
-    const uint32_t m0 = s.tri_mat[(size_t)idx * 3];
+    const uint4 rc = rec[2];
+    const uint32_t idx = ref & 0x0fffffffu;
+    const V3 p0 = v3(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z));
+    const V3 p1 = v3(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z));
+    const V3 p2 = v3(__uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z));
+    const uint32_t flags = (ref >> 28) & 3u;
+    const uint32_t m0 = rb.w;
     g.mat0 = m0;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
     if (flags & (RTX_TRI_VERTEX_NORMAL | RTX_TRI_VERTEX_MATERIAL)) weighted_areas(p0, p1, p2, g.p, a0, a1, a2, g.panic);
@@ -69,8 +72,8 @@ RTX_D HitGeom hit_geometry(const DevScene& s, int prim_id, V3 o, V3 d, float t, 
     if (want_color) {
         if (flags & RTX_TRI_VERTEX_MATERIAL) {  // poly.rs:91-94
             const rtx_material* ma = material_or_null(s, m0);
-            const rtx_material* mb = material_or_null(s, s.tri_mat[(size_t)idx * 3 + 1]);
-            const rtx_material* mc = material_or_null(s, s.tri_mat[(size_t)idx * 3 + 2]);
+            const rtx_material* mb = material_or_null(s, rc.w);
+            const rtx_material* mc = material_or_null(s, rec[3].x);
             if (!ma || !mb || !mc) g.panic = true;
             const Col da = ma ? col_raw(ma->diffuse) : col_new();
             const Col db = mb ? col_raw(mb->diffuse) : col_new();
