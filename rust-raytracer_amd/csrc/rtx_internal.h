@@ -162,6 +162,7 @@ struct rtx_context {
     void* pinned = nullptr;       // page-locked staging for counter read-backs and the cameras of a batch of frames
     void* cam_dev = nullptr;      // device copy of those cameras (a page for the synchronous path, one per frame in flight)
     bool has_secondary = false;   // some material reflects or refracts (src/lib.rs:230,241)
+    uint32_t shade_a_resident = 0;   // workgroups of k_shade_a a CU keeps resident (asked once; sizes its launches)
 
     // knobs (rtx_set_option)
     int64_t opt_force_mode = 0;   // 0 auto, 1 exhaustive, 2 bvh

@@ -1557,6 +1557,19 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         uint32_t n_rays = n, levels_done = 0;
         if (levels == 0)   // depth 0: primary rays are traced, every pixel stays black (lib.rs:203-205)
             launch_closest(ctx, wk, 0, n_rays, gen, nullptr, false, st);
+        // k_shade_a walks its chunks in a loop with a workgroup-wide wait per chunk, so its time goes with
+        // (rounds of resident workgroups) x (chunks per workgroup). Measured on the eight-frame batch (16 200 chunks, 5
+        // workgroups per CU resident): 187 / 167 / 151 / 195 / 168 us with 3 / 4 / 5 / 6 / 8 workgroups per CU and 166 with
+        // 4096 workgroups -- one round wins when a workgroup has many chunks to even out; with 6 chunks per workgroup (a
+        // four-frame batch) the 4096 win, because workgroups that start as others end balance the load. k_shade_b, whose
+        // passes are independent, keeps the 4096 (one round of resident workgroups measured 195 us against 141).
+        if (ctx->shade_a_resident == 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade_a, RTX_BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+            (void)hipGetLastError();
+            ctx->shade_a_resident = (uint32_t)per_cu;
+        }
+        const uint32_t shade_resident_a = (uint32_t)ctx->num_cus * ctx->shade_a_resident, shade_cap_b = 4096u;
         for (uint32_t level = 0; level < levels; ++level) {
             const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
             hipEvent_t a = no_kt ? nullptr : ev.next(), b = no_kt ? nullptr : ev.next();
@@ -1568,7 +1581,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             UnitOrder* uo1 = nullptr;
             launch_closest(ctx, wk, qi, n_rays, pg, uo0, true, st, a, b);
             closest_events.emplace_back(a, b);
-            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, 4096) + (uo0 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
+            const uint64_t shade_chunks = ((uint64_t)n_rays + RTX_BLOCK * kShadeItems - 1) / (RTX_BLOCK * kShadeItems);
+            const uint32_t shade_cap_a = (shade_chunks >= 8ull * shade_resident_a) ? shade_resident_a : 4096u;
+            hipLaunchKernelGGL(k_shade_a, dim3(blocks_for((n_rays + kShadeItems - 1) / kShadeItems, shade_cap_a) + (uo0 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi,
                                PixMap{level == 0 ? 1u : 0u, rank, world, tiles_x, w, n_frames, (uint32_t)rays_per_frame}, pg, out_map, uo0);
             if (s.n_lights > 0) {
                 hipEvent_t c = no_kt ? nullptr : ev.next(), d = no_kt ? nullptr : ev.next();
@@ -1578,7 +1593,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 launch_shadow(ctx, wk, depth - level, tasks, n_slots, any_shadow, uo1, st, c, d);
                 shadow_events.emplace_back(c, d);
             }
-            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, 4096) + (uo1 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
+            hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, shade_cap_b) + (uo1 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
                                out_map, single_level ? 1 : 0, uo1);
             if (single_level) break;
             hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
