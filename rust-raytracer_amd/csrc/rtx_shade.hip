@@ -1457,6 +1457,12 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     if (rc != RTX_OK) return rc;
     wk.n_samples = n_samples;
     wk.area_off = (s.n_area_lights && samples == 0) ? 1u : 0u;
+    if (ctx->shade_a_resident == 0) {   // workgroups of k_shade_a a CU keeps resident: asked once, before anything is recorded
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade_a, RTX_BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        (void)hipGetLastError();
+        ctx->shade_a_resident = (uint32_t)per_cu;
+    }
 
     const CamSetup cam = make_cam(cameras ? cameras[0] : ctx->camera, w, h);
     const CamSetup* d_cams = nullptr;
@@ -1563,12 +1569,6 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         // 4096 workgroups -- one round wins when a workgroup has many chunks to even out; with 6 chunks per workgroup (a
         // four-frame batch) the 4096 win, because workgroups that start as others end balance the load. k_shade_b, whose
         // passes are independent, keeps the 4096 (one round of resident workgroups measured 195 us against 141).
-        if (ctx->shade_a_resident == 0) {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade_a, RTX_BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-            (void)hipGetLastError();
-            ctx->shade_a_resident = (uint32_t)per_cu;
-        }
         const uint32_t shade_resident_a = (uint32_t)ctx->num_cus * ctx->shade_a_resident, shade_cap_b = 4096u;
         for (uint32_t level = 0; level < levels; ++level) {
             const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
