@@ -107,7 +107,8 @@ struct DevScene {
 // of a wavefront is one fully coalesced 1 KiB (or 512 B) transaction.
 //   o[i]   = (origin.xyz, bits(link))   link: level 0 = pixel slot; deeper = parent pool slot | (branch << 31)
 //   d[i]   = (dir.xyz,    bits(flags))  flags bit0: ray is in vacuum (src/ray.rs:9); bit1: ray is valid
-//   hit[i] = (prim_id, bits(t))         written by the traversal kernel
+//   hit[i] = (prim_id, bits(t))         written by the traversal kernel (when the launch keeps a hit mask per work
+//                                       unit for the shading pass: for rays that hit something only)
 struct RayQueue {
     float4* o;
     float4* d;

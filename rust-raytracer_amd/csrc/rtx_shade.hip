@@ -207,8 +207,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(PrimaryGen pg, Work wk, ui
 // Cost-ordered units. A launch ends with its slowest units, and those are slow because
 // their rays are (a few rays grazing the surface take ten times the steps of the rest), so
 // the launch is shortest when the expensive units start first. What a unit costs is not
-// known before it ran, but the previous frame knows: every unit records its duration, a
-// small kernel (k_order_units, off the critical path) sorts the units by it, and the next
+// known before it ran, but the previous frame knows: every unit records its duration, one
+// workgroup of the shading launch that follows (order_units) sorts the units by it, and the next
 // launch of the same kind hands units out in that order whenever its unit count equals the
 // recorded one -- a re-render, the next sample of the same view, or the next frame of a
 // slowly moving camera. Any permutation of the units gives the same image; with no valid
@@ -302,8 +302,9 @@ struct UnitQueue {
 // Sorts the groups of the last launch by recorded cost, most expensive first, and clears the
 // costs for the next recording: a stable counting sort into 16 classes (two per octave below
 // the largest cost), so groups of similar cost keep their index order. Work for ONE workgroup
-// of 256 threads; the shading kernel that follows a traversal launch gives it to one of its
-// workgroups, which costs no launch and hides behind the other workgroups.
+// of 256 threads; the shading launch that follows a traversal launch carries one workgroup more
+// than its shading needs, and that workgroup does nothing else: no launch of its own, and the
+// sort runs beside the shading.
 constexpr int kOrderThreads = RTX_BLOCK, kOrderClasses = 16;
 // Half-octave code of a cost: 2 * floor(log2 c) + the bit below the leading one (0 for c <= 1), at most 63.
 RTX_D uint32_t cost_code(uint32_t c) {
@@ -331,8 +332,8 @@ RTX_D void order_units(UnitOrder* uo) {
     for (int k = 0; k < kOrderClasses; ++k) offs[k * kOrderThreads + t] = 0;
     __syncthreads();
     // A thread's costs are read once, four per load and all loads independent, and kept as one-byte codes when they
-    // fit its registers (up to 16384 groups: four 1080p frames): the sort runs inside a shading kernel that may be
-    // short, so its own latency counts. cost[] is padded to a multiple of 4 entries (see unit_order).
+    // fit its registers (up to 16384 groups: four 1080p frames): the sort runs beside a shading launch that may be
+    // short (tens of microseconds for one frame), so its own latency counts. cost[] is padded to a multiple of 4 entries (see unit_order).
     constexpr uint32_t kHeld = 16;   // registers: 4 codes each
     uint32_t held[kHeld];
     const bool fits = per <= 4 * kHeld;
