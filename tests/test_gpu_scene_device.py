@@ -155,3 +155,18 @@ def test_depth_above_the_limit_where_nothing_recurses(rtx, gpu_ctx_factory):
     with pytest.raises(rtx.RtxError) as e:
         ctx2.render(32, 32, 100, 10)
     assert e.value.status == 6
+
+
+def test_leaf_size_is_not_an_option(rtx, gpu_ctx_factory):
+    """A leaf of the tree is one primitive (the fetch of a leaf reference is the primitive test's operand):
+    "tune3" accepts that value and nothing else, and the frame does not depend on setting it."""
+    flat = rtx.parse_scene(scene_path("test04"))
+    ctx = gpu_ctx_factory(flat)
+    a, _ = ctx.render(64, 64, 10, 1)
+    ctx.set_option("tune3", 1)
+    with pytest.raises(rtx.RtxError) as e:
+        ctx.set_option("tune3", 4)
+    assert e.value.status == 1
+    ctx.build()
+    b, _ = ctx.render(64, 64, 10, 1)
+    assert np.array_equal(a, b)
