@@ -9,8 +9,9 @@ level of rays is traced: primary + 4 shadow rays per hit). One step = one batch 
 of a 20-step run is about a second, not ten milliseconds), rendered eight per GPU and set of
 launches (--frames-per-batch), scene and BVH resident in HBM; batches are pipelined (the next
 one is enqueued while the last one is collected) and all of them are complete before the clock stops. N > 1: the frame is sharded by interleaved 8x8 tiles,
-the scene is broadcast once from rank 0 over RCCL and every frame's tile slabs are all-gathered
-and assembled (strong scaling: the frame is fixed).
+the scene is broadcast once from rank 0 over RCCL and the tile slabs of a batch's frames are exchanged
+so that every frame is assembled whole on one rank (an all-to-all: rank d gets the slabs of its run of the
+batch's frames; --exchange all_gather delivers every frame to every rank). Strong scaling: the frame is fixed.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (fresh child
 processes, one GPU each, started before this process touches a GPU); under torchrun the ranks
@@ -155,6 +156,10 @@ def main():
                     help="N > 1: who runs the exchange steps. torch: torch.distributed broadcast / all-gather (RCCL underneath); "
                          "abi: the library's own entry points (rtx_comm_init, rtx_scene_broadcast, rtx_gather_frame: RCCL "
                          "broadcast and gather-to-root), as a Rust or C++ host would call them")
+    ap.add_argument("--exchange", type=str, default="all_to_all", choices=("all_to_all", "all_gather"),
+                    help="N > 1, torch collectives, batches of frames: all_to_all = frame f of a batch is assembled on rank "
+                         "f // (frames per batch / N) -- every rank receives the slabs of ITS frames only, 1/N of what an "
+                         "all-gather delivers to every rank -- all_gather = every rank receives and assembles every frame")
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5),
                     help="BASELINE configuration: 3 = 1M triangles at 1080p (default, the single-GPU bench workload), 4 = 16M triangles + "
                          "64 glass spheres at 4K depth 5, 5 = 62.72M triangles + 1.28M spheres at 8K depth 5")
@@ -275,6 +280,12 @@ def main():
     else:
         fpb = 1
     fps = (fps + fpb - 1) // fpb * fpb      # a step is a whole number of batches
+    # Exchange step of a sharded batch. A frame has to be whole on ONE GPU, not on all of them: with all_to_all the
+    # batch's frames are dealt out in equal runs, rank d assembles frames [d * fpr, (d + 1) * fpr) and receives only
+    # those frames' slabs (N = 8: 50 MB in and out per rank and batch; an all-gather delivers 400 MB to every rank,
+    # and every rank then assembles all 64 frames).
+    a2a = multi and not abi and args.exchange == "all_to_all" and fpb > 1 and fpb % world == 0
+    fpr = fpb // world if a2a else fpb      # frames this rank assembles per batch
     # Frames are pipelined: while the GPU renders frame k the host collects frame k - 1 (and, for
     # N > 1, its slabs travel while frame k renders and frame k - 2 is assembled). Every frame that
     # was enqueued inside the timed region is complete before the clock stops.
@@ -283,8 +294,8 @@ def main():
     ring = 2 * len(ctxs) if multi else in_flight + 2
     images = [torch.zeros(fpb * h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
     slabs = [torch.zeros(fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
-    gathered = [torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
-    gathered_host = torch.zeros(world * fpb * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
+    gathered = [torch.zeros(world * fpr * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
+    gathered_host = torch.zeros(world * fpr * tpr * 192, dtype=torch.uint8).pin_memory() if gloo else None
     torch.cuda.synchronize()      # torch clears these on its own stream; the library's streams do not wait for it
     image = images[0]
     acc = {}
@@ -337,7 +348,7 @@ def main():
         gather_done[idx] = ev
         asm_stream.wait_event(ev)                       # ... and so does the stream that assembles
         if fpb > 1:
-            asm_ctx.assemble_frames_async(fpb, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+            asm_ctx.assemble_frames_async(fpr, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
         else:
             asm_ctx.assemble_tiles_async(w, h, world, gathered[idx].data_ptr(), image.data_ptr())
         ev2 = event_pool[idx][1]
@@ -356,16 +367,22 @@ def main():
             ctx.gather_frames(fpb, w, h, slabs[idx].data_ptr(), image.data_ptr(), 0)
             return
         if gloo:
-            dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
+            if a2a:
+                dist.all_to_all_single(gathered_host, slabs[idx].cpu())
+            else:
+                dist.all_gather_into_tensor(gathered_host, slabs[idx].cpu())
             gathered[idx].copy_(gathered_host)
             torch.cuda.current_stream().synchronize()
-            ctx.assemble_frames_async(fpb, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
+            ctx.assemble_frames_async(fpr, w, h, world, gathered[idx].data_ptr(), image.data_ptr())
             torch.cuda.ExternalStream(ctx.stream(), device=dev).synchronize()
             return
         finish_gather()            # the frame before it
         if assemble_done[idx] is not None:              # the assembly that last read this gather buffer
             torch.cuda.current_stream().wait_event(assemble_done[idx])
-        state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
+        if a2a:
+            state["gather"] = (dist.all_to_all_single(gathered[idx], slabs[idx], async_op=True), idx)
+        else:
+            state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
 
     def step():     # one batch of `fpb` frames; a bench step is `fps` frames
         k = state["enqueued"]
@@ -434,7 +451,7 @@ def main():
         torch.cuda.synchronize()      # torch fills the buffer on ITS stream; the library renders on its own
         ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
         torch.cuda.synchronize()
-        sharded_equal = all(bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3])) for f in range(fpb))
+        sharded_equal = all(bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3])) for f in range(fpr))
     gather_isolated_ms = None
     if abi:                    # the exchange step alone: 10 gathers to the root, nothing else on the GPU
         torch.cuda.synchronize()
@@ -451,7 +468,10 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            dist.all_gather_into_tensor(gathered[0], slabs[0])
+            if a2a:
+                dist.all_to_all_single(gathered[0], slabs[0])
+            else:
+                dist.all_gather_into_tensor(gathered[0], slabs[0])
         e1.record()
         torch.cuda.synchronize()
         gather_isolated_ms = e0.elapsed_time(e1) / 10
@@ -550,7 +570,8 @@ def main():
                                    % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps, fpb),
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth, "frames_per_step": fps,
                        "frames_per_batch": fpb, "batch_latency_ms_approx": elapsed / frames * 1e3 * fpb * (len(ctxs) + 1),
-                       "parallelism": ("tile-sharded x%d (%s, %s collectives)" % (world, args.backend, args.collectives)) if multi else "single GPU",
+                       "parallelism": ("tile-sharded x%d (%s, %s collectives, %s)" % (world, args.backend, args.collectives,
+                                       "all-to-all: each frame assembled on one rank" if a2a else "gather to the root" if abi else "all-gather")) if multi else "single GPU",
                        "ranks": world, "batches_in_flight_per_gpu": len(ctxs) + 1},
             "ms_per_frame": elapsed / frames * 1e3,
             "rays_per_frame": total_traced / frames,
