@@ -11,7 +11,8 @@ launches (--frames-per-batch), scene and BVH resident in HBM; batches are pipeli
 one is enqueued while the last one is collected) and all of them are complete before the clock stops. N > 1: the frame is sharded by interleaved 8x8 tiles,
 the scene is broadcast once from rank 0 over RCCL and the tile slabs of a batch's frames are exchanged
 so that every frame is assembled whole on one rank (an all-to-all: rank d gets the slabs of its run of the
-batch's frames; --exchange all_gather delivers every frame to every rank). Strong scaling: the frame is fixed.
+batch's frames; --exchange all_gather delivers every frame to every rank). A step is --frames-per-step x N frames, so
+the work per GPU and step does not depend on N (weak scaling: `value` = rays of all ranks / time).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (fresh child
 processes, one GPU each, started before this process touches a GPU); under torchrun the ranks
@@ -195,6 +196,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.frames_per_step <= 0:
+        fps *= world      # a step is the same amount of work per GPU whatever N is: N x as many frames, each cut into N shares
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     multi = world > 1 or args.rehearse_dist        # the sharded code path (also with a single rank when rehearsing)
@@ -561,7 +564,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",      # per-GPU work per step is fixed: a step is 100 x N frames, a rank renders 1/N of each
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
