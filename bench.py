@@ -192,6 +192,7 @@ def main():
         os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", args.lib)
     fps = args.frames_per_step if args.frames_per_step > 0 else {3: 100, 4: 10, 5: 4}[args.config]
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # multi-process GPU work here needs dmabuf IPC (RCCL over xGMI)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
