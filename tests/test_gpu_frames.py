@@ -164,6 +164,37 @@ def test_assembly_of_batches(rtx, w, h, world):
         assert torch.equal(one, whole)
 
 
+@pytest.mark.parametrize("world,n", [(2, 4), (3, 6)])
+def test_all_to_all_exchange_of_a_batch(rtx, world, n):
+    """The exchange in which every frame is assembled on ONE rank: the slabs of a batch lie frame by frame, so an
+    all-to-all with equal splits hands rank d the slabs of frames [d n/world, (d+1) n/world) from every rank, laid out
+    [source rank][frame][tiles] -- which is what rtx_assemble_frames_async takes for n/world frames. The collective is
+    played here with tensor slices (bench.py runs the real one, over RCCL or gloo)."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test06"))
+    w, h = 100, 52
+    cams = _cameras(rtx, flat, n)
+    fpr = n // world
+    with rtx.Context(0) as ctx:
+        ctx.set_scene(flat)
+        ctx.build()
+        want = torch.zeros(n * h * w * 3, dtype=torch.uint8, device="cuda:0")
+        ctx.render_frames(n, cams, w, h, 5, 1, 0, 1, want.data_ptr(), True)
+        tpr = rtx.tiles_per_rank(w, h, world)
+        slabs = torch.full((world, n, tpr * 192), 5, dtype=torch.uint8, device="cuda:0")       # slabs[r] = what rank r rendered
+        for r in range(world):
+            ctx.render_frames(n, cams, w, h, 5, 1, r, world, slabs[r].data_ptr(), False)
+        torch.cuda.synchronize()
+        for d in range(world):
+            # all_to_all_single(recv, slabs[r]) on every rank r: chunk d of slabs[r] lands in chunk r of rank d's recv
+            recv = torch.stack([slabs[r].view(world, fpr * tpr * 192)[d] for r in range(world)]).contiguous()
+            got = torch.full((fpr * h * w * 3,), 3, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.assemble_frames_async(fpr, w, h, world, recv.data_ptr(), got.data_ptr())
+            torch.cuda.ExternalStream(ctx.stream()).synchronize()
+            assert torch.equal(got, want.view(world, fpr * h * w * 3)[d]), "frames of rank %d" % d
+
+
 def test_largest_batch(rtx):
     """RTX_MAX_BATCH_FRAMES frames with a camera each: every frame equals the frame of a batch of one."""
     torch = pytest.importorskip("torch")
