@@ -330,8 +330,9 @@ def main():
     # slab k is read by all-gather k and rewritten by render k + ring; gathered k is written by all-gather k,
     # read by assembly k and rewritten by all-gather k + ring.
     lib_streams = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs] if (multi and not gloo and not abi) else None
-    # The assembly of a gathered batch (a copy kernel over world x the rank's slabs: 0.8 GB of traffic per batch on 8
-    # ranks) runs on a context of its own, i.e. on its own stream, beside the rendering contexts' traversal kernels.
+    # The assembly of a received batch (a copy kernel over the slabs of this rank's frames; with --exchange all_gather
+    # over world x the rank's slabs: 0.8 GB of traffic per batch on 8 ranks) runs on a context of its own, i.e. on its
+    # own stream, beside the rendering contexts' traversal kernels.
     asm_ctx = ctx.clone() if lib_streams is not None else None
     asm_stream = torch.cuda.ExternalStream(asm_ctx.stream(), device=dev) if asm_ctx is not None else None
     TIMED_EVERY = 16
