@@ -276,12 +276,14 @@ def main():
     # Larger launches also lose less at their ends (a launch finishes with its slowest wavefronts while the rest of the
     # GPU idles), so the 1080p configuration renders 8 frames per batch and GPU (64 frames per batch, the library's limit,
     # on 8 ranks) -- measured 8.9 / 10.5 / 13.4 / 14.3 Grays/s with 1 / 2 / 4 / 8 frames per
-    # batch on one GPU. The 4K and 8K configurations render frame by frame.
+    # batch on one GPU. The 4K configuration renders two frames per batch and GPU, the 8K configuration frame by frame.
     if args.frames_per_batch > 0:
         fpb = args.frames_per_batch
     elif args.config == 3:
         fpb = min(8 * world, rtx.MAX_BATCH_FRAMES)
-    else:
+    elif args.config == 4:      # two 4K frames fill the default ray batch; their deeper levels' launches are twice as large too (+16 %)
+        fpb = min(2 * world, rtx.MAX_BATCH_FRAMES)
+    else:                       # one 8K frame is two ray batches by itself
         fpb = 1
     fps = (fps + fpb - 1) // fpb * fpb      # a step is a whole number of batches
     # Exchange step of a sharded batch. A frame has to be whole on ONE GPU, not on all of them: with all_to_all the
@@ -486,7 +488,7 @@ def main():
         src_hash = source_hash()
         # dominant kernel = the traversal kernel with the larger share of device time on this rank
         if acc["shadow_ms"] >= acc["closest_ms"] and acc["shadow_launches"]:
-            kname, kkey, kms, kl, krays = "k_shadow (any-hit traversal)", "shadow", acc["shadow_ms"], acc["shadow_launches"], acc["shadow_rays"]
+            kname, kkey, kms, kl, krays = "k_shadow (shadow-ray traversal: any-hit, or closest-hit where materials are transparent)", "shadow", acc["shadow_ms"], acc["shadow_launches"], acc["shadow_rays"]
         else:
             kname, kkey, kms, kl, krays = ("k_trace_queue (closest-hit traversal)", "closest", acc["closest_ms"], acc["closest_launches"],
                                            acc["closest_rays"])
