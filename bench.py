@@ -4,15 +4,19 @@
 Workload (BASELINE.json configs[2], the largest single-GPU configuration): synthetic
 1 002 528-triangle tessellated height field + 4 point lights at 1920x1080, depth 10
 (the reference's default; the scene has no reflective or refractive material, so one
-level of rays is traced: primary + 4 shadow rays per hit). One step = one batch of
---frames-per-step frames of that view (default 100 for this workload, so that the timed region
-of a 20-step run is about a second, not ten milliseconds), rendered eight per GPU and set of
-launches (--frames-per-batch), scene and BVH resident in HBM; batches are pipelined (the next
+level of rays is traced: primary + 4 shadow rays per hit). One step = --frames-per-step
+frames (default 100 for this workload, so that the timed region of a 20-step run is about a
+second, not ten milliseconds) of a camera path around the scene -- every frame has its own
+camera (--cameras fixed: the scene's camera for every frame) -- rendered eight per GPU and set of
+launches (--frames-per-batch), scene and BVH resident in HBM; the same path rendered one frame
+per set of launches is reported beside it (`value_single_frame`). Batches are pipelined (the next
 one is enqueued while the last one is collected) and all of them are complete before the clock stops. N > 1: the frame is sharded by interleaved 8x8 tiles,
 the scene is broadcast once from rank 0 over RCCL and the tile slabs of a batch's frames are exchanged
 so that every frame is assembled whole on one rank (an all-to-all: rank d gets the slabs of its run of the
 batch's frames; --exchange all_gather delivers every frame to every rank). A step is --frames-per-step x N frames, so
 the work per GPU and step does not depend on N (weak scaling: `value` = rays of all ranks / time).
+--scaling strong: the step is the same --frames-per-step frames whatever N is, one frame per set of launches, each
+frame cut into N shares (BASELINE configs[3] as written: one 4K depth-5 frame tile-sharded over 2/4/8 GPUs).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (fresh child
 processes, one GPU each, started before this process touches a GPU); under torchrun the ranks
@@ -52,12 +56,34 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT loading the HIP runtime (the ranks are started from this process,
+    which must never have touched a GPU): the kernel driver's topology lists every node, GPUs are the nodes with SIMDs;
+    a *_VISIBLE_DEVICES list narrows that. None when the topology cannot be read (the ranks then find out themselves)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except Exception:
+            return None
+    return n
+
+
 def launch_ranks(n, argv, backend):
     """Parent of a `--gpus N` run that was not started by torchrun: starts N fresh ranks (this process has
     not touched a GPU and never will), passes rank 0's JSON line through and fails if any rank fails."""
-    import torch
-    have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-    if backend != "gloo" and have < n:
+    have = visible_gpus()
+    if backend != "gloo" and have is not None and have < n:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --backend gloo to rehearse ranks sharing a GPU)" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -173,9 +199,16 @@ def main():
                     help="with one process: run the multi-GPU code path (process group of one rank, tile slab, all-gather, "
                          "assembly) instead of the single-GPU one; for checking that path on a one-GPU box")
     ap.add_argument("--frames-per-batch", type=int, default=0,
-                    help="frames rendered as one set of launches (rtx_render_frames_async); 0 = 4 per GPU for the 1080p "
-                         "configuration (so that a rank's share of a batch is as much work as four whole frames), 1 otherwise")
+                    help="frames rendered as one set of launches (rtx_render_frames_async); 0 = 8 per GPU for the 1080p "
+                         "configuration (so that a rank's share of a batch is as much work as eight whole frames), 2 per GPU for "
+                         "config 4, 1 for config 5 and with --scaling strong")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
+    ap.add_argument("--cameras", type=str, default="path", choices=("path", "fixed"),
+                    help="path (default): every frame has its own camera, frame k of a fly-around of the scene (synth.camera_path); "
+                         "fixed: the scene's camera for every frame (the frames of a batch are then copies of one frame)")
+    ap.add_argument("--scaling", type=str, default="weak", choices=("weak", "strong"),
+                    help="weak (default): a step is --frames-per-step x N frames, rendered in batches, so the work per GPU does not depend on N; "
+                         "strong: a step is --frames-per-step frames whatever N is, one frame per set of launches, each frame cut into N shares")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -197,7 +230,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.frames_per_step <= 0:
+    strong = args.scaling == "strong"
+    if args.frames_per_step <= 0 and not strong:
         fps *= world      # a step is the same amount of work per GPU whatever N is: N x as many frames, each cut into N shares
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -270,6 +304,11 @@ def main():
     scene_setup_ms = (time.time() - t_s0) * 1e3     # scene into the context + tree build, per rank
     ctxs = [ctx] + [ctx.clone() for _ in range(n_contexts - 1)]
     w, h = args.width, args.height
+
+    class _Cam:      # the scene's camera, known on every rank (the generator is deterministic; only rank 0 built the arrays)
+        camera = (flat.camera if flat is not None else scene_meta["camera"] if scene_meta is not None
+                  else synth.heightfield_scene(4).camera)
+    flat_cam = _Cam
     tpr = rtx.tiles_per_rank(w, h, world)
     # Frames per batch: a rank's 1/N share of one small frame cannot fill a GPU (its launches are as long as their
     # longest ray chains however few rays they hold), so sharded runs render the shares of several frames at once.
@@ -279,6 +318,8 @@ def main():
     # batch on one GPU. The 4K configuration renders two frames per batch and GPU, the 8K configuration frame by frame.
     if args.frames_per_batch > 0:
         fpb = args.frames_per_batch
+    elif strong:                # the frame is the unit: one per set of launches, cut N ways
+        fpb = 1
     elif args.config == 3:
         fpb = min(8 * world, rtx.MAX_BATCH_FRAMES)
     elif args.config == 4:      # two 4K frames fill the default ray batch; their deeper levels' launches are twice as large too (+16 %)
@@ -297,7 +338,9 @@ def main():
     # was enqueued inside the timed region is complete before the clock stops.
     in_flight = max(1, len(ctxs))     # frames enqueued beyond the one being collected
     # (sharded runs: two slabs per context, so that a context's recorded frames see the same two buffers again)
-    ring = 2 * len(ctxs) if multi else in_flight + 2
+    # (and at least in_flight + 2: slab k is read by exchange k, which is only waited for when batch k + 1 is collected,
+    # i.e. after render k + in_flight + 1 was enqueued -- that render must not be the one that rewrites slab k)
+    ring = max(2 * len(ctxs), in_flight + 2) if multi else in_flight + 2
     images = [torch.zeros(fpb * h * w * 3, dtype=torch.uint8, device=dev) for _ in range(in_flight + 1)]
     slabs = [torch.zeros(fpb * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
     gathered = [torch.zeros(world * fpr * tpr * 192, dtype=torch.uint8, device=dev) for _ in range(ring)] if multi else None
@@ -391,12 +434,27 @@ def main():
         else:
             state["gather"] = (dist.all_gather_into_tensor(gathered[idx], slabs[idx], async_op=True), idx)
 
+    # Cameras: batch k renders frames [k * fpb, (k + 1) * fpb) of a fly-around of the scene, one camera per frame
+    # (every rank computes the same path); --cameras fixed renders the scene's camera every time.
+    use_path = args.cameras == "path"
+    path_cache = {}
+
+    def cams_of(k):
+        if not use_path:
+            return None
+        if k not in path_cache:
+            if len(path_cache) > 4096:
+                path_cache.clear()
+            path_cache[k] = synth.camera_path(flat_cam, k * fpb, fpb)
+        return path_cache[k]
+
     def step():     # one batch of `fpb` frames; a bench step is `fps` frames
         k = state["enqueued"]
         state["enqueued"] += 1
+        cams = cams_of(k)
         if not multi:   # single GPU: the frames are written row-major in place
-            if fpb > 1:
-                ctxs[k % len(ctxs)].render_frames_async(fpb, None, w, h, args.depth, 10, 0, 1, images[k % len(images)].data_ptr(), True)
+            if fpb > 1 or cams is not None:
+                ctxs[k % len(ctxs)].render_frames_async(fpb, cams, w, h, args.depth, 10, 0, 1, images[k % len(images)].data_ptr(), True)
             else:
                 ctxs[k % len(ctxs)].render_device_async(w, h, args.depth, 10, images[k % len(images)].data_ptr())
         else:
@@ -410,8 +468,8 @@ def main():
             if timing_state[c] != timed:
                 ctxs[c].set_option("kernel_timing", timed)
                 timing_state[c] = timed
-            if fpb > 1:
-                ctxs[c].render_frames_async(fpb, None, w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr(), False)
+            if fpb > 1 or cams is not None:
+                ctxs[c].render_frames_async(fpb, cams, w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr(), False)
             else:
                 ctxs[c].render_tiles_async(w, h, args.depth, 10, rank, world, slabs[k % ring].data_ptr())
         if state["enqueued"] - state["collected"] > in_flight:
@@ -453,12 +511,25 @@ def main():
         total_traced = float(tr.item())
 
     sharded_equal = None
-    if multi and rank == 0:   # outside the timed region: the assembled frame against a single-GPU frame
+    last_cams = cams_of(state["enqueued"] - 1)      # cameras of the batch whose frames `image` holds
+    if multi and rank == 0:   # outside the timed region: the assembled frames against single-GPU frames with the same cameras
         whole = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()      # torch fills the buffer on ITS stream; the library renders on its own
-        ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
+        sharded_equal = True
+        for f in range(fpr):          # rank 0 holds the first fpr frames of the batch (all of them without the all-to-all)
+            if last_cams is None:
+                ctx.render_device(w, h, args.depth, 10, whole.data_ptr())
+            else:
+                ctx.render_frames(1, [last_cams[f]], w, h, args.depth, 10, 0, 1, whole.data_ptr(), True)
+            torch.cuda.synchronize()
+            sharded_equal = sharded_equal and bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3]))
+        del whole
+    frames_differ = None
+    if rank == 0 and fpb > 1 and (not multi or fpr > 1):      # the frames of a batch are different frames (or, with --cameras fixed, copies)
         torch.cuda.synchronize()
-        sharded_equal = all(bool(torch.equal(whole, image[f * h * w * 3:(f + 1) * h * w * 3])) for f in range(fpr))
+        frames_differ = not bool(torch.equal(image[:h * w * 3], image[h * w * 3:2 * h * w * 3]))
+        if use_path and not frames_differ:
+            raise SystemExit("bench.py: frames 0 and 1 of a batch with distinct cameras came out identical")
     gather_isolated_ms = None
     if abi:                    # the exchange step alone: 10 gathers to the root, nothing else on the GPU
         torch.cuda.synchronize()
@@ -485,7 +556,7 @@ def main():
     if rank == 0:
         n_prims = flat.n_prims
         b_ray = synth.bytes_per_ray(n_prims)
-        src_hash = source_hash()
+        src_hash = rtx.source_hash()      # of the library that is loaded, not of the source tree
         # dominant kernel = the traversal kernel with the larger share of device time on this rank
         if acc["shadow_ms"] >= acc["closest_ms"] and acc["shadow_launches"]:
             kname, kkey, kms, kl, krays = "k_shadow (shadow-ray traversal: any-hit, or closest-hit where materials are transparent)", "shadow", acc["shadow_ms"], acc["shadow_launches"], acc["shadow_rays"]
@@ -501,6 +572,8 @@ def main():
         workload_key = "config%d_grid%d_%dx%d_depth%d_spec%g_glass%d" % (args.config, args.grid, w, h, args.depth, args.spec, args.glass)
         if fpb > 1:
             workload_key += "_fpb%d" % fpb      # counters per launch belong to a launch of that many frames
+        if use_path:
+            workload_key += "_campath"          # ... of that many DIFFERENT frames
         default_workload = (args.config == 3 and args.grid == 708 and (w, h) == (1920, 1080) and args.depth == 10
                             and args.spec == 0.0 and args.glass == 0 and not multi)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -568,13 +641,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",      # per-GPU work per step is fixed: a step is 100 x N frames, a rank renders 1/N of each
+            # weak: per-GPU work per step is fixed (a step is 100 x N frames, a rank renders 1/N of each);
+            # strong: the step is the same frames whatever N is
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "synthetic %d-triangle tessellated height field%s + 4 point lights at %dx%d, depth %d, "
-                                   "LBVH traversal, scene and BVH resident in HBM; one step = %d frames, rendered %d per set of launches"
-                                   % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps, fpb),
+                                   "LBVH traversal, scene and BVH resident in HBM; one step = %d frames, rendered %d per set of launches; %s"
+                                   % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps, fpb,
+                                      ("every frame has its own camera (frame k of a fly-around: the scene's camera turned by 0.004 k rad about "
+                                       "the vertical axis), so a batch holds %d DIFFERENT frames" % fpb) if use_path
+                                      else ("the scene's camera for every frame: a batch holds %d COPIES of one frame" % fpb)),
+                       "cameras": "path: %d distinct cameras per batch" % fpb if use_path else "fixed: %d copies per batch" % fpb,
+                       "batch_frames_differ": frames_differ,
                        "n_prims": n_prims, "width": w, "height": h, "depth": args.depth, "frames_per_step": fps,
                        "frames_per_batch": fpb, "batch_latency_ms_approx": elapsed / frames * 1e3 * fpb * (len(ctxs) + 1),
                        "parallelism": ("tile-sharded x%d (%s, %s collectives, %s)" % (world, args.backend, args.collectives,
@@ -596,10 +676,62 @@ def main():
                         "closest_rays_per_launch": closest_per_launch, "shadow_rays_per_launch": shadow_per_launch},
             "roofline": roof,
         }
-        if default_workload and len(ctxs) == 1 and not args.no_extras:
-            # Supplementary, outside the timed region and not `value`: the same frames rendered one per set of launches
-            # (the configuration the headline used before frames were batched), on one context and alternating between
-            # three contexts (streams), where one frame's kernel tails overlap the next frame's kernels.
+        single_gpu_extras = (not multi) and len(ctxs) == 1 and not args.no_extras
+        if single_gpu_extras:
+            # First-class beside `value`: the SAME camera path rendered one frame per set of launches on one context
+            # (two frames in flight) -- the configuration as BASELINE words it, one frame at a time. Outside the timed
+            # region of `value`, timed the same way (wall clock around enqueue ... last frame collected).
+            try:
+                n1 = {3: 300, 4: 20, 5: 6}[args.config]
+                warm1 = {3: 12, 4: 2, 5: 1}[args.config]
+                path1 = synth.camera_path(flat_cam, 0, n1 + warm1) if use_path else None
+                bufs1 = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(3)]
+                torch.cuda.synchronize()
+
+                def enqueue1(c, k, buf):
+                    if path1 is None:
+                        c.render_device_async(w, h, args.depth, 10, buf.data_ptr())
+                    else:
+                        c.render_frames_async(1, [path1[k]], w, h, args.depth, 10, 0, 1, buf.data_ptr(), True)
+
+                def run1(k0, n):      # frame by frame on one context, two frames in flight
+                    tot = {"closest_ms": 0.0, "shadow_ms": 0.0, "frames": 0, "traced": 0}
+                    def take(st1):
+                        tot["closest_ms"] += st1.closest_ms; tot["shadow_ms"] += st1.shadow_ms
+                        tot["frames"] += 1; tot["traced"] += st1.traced_rays
+                    for k in range(n):
+                        if k >= 2:
+                            take(ctx.render_wait())
+                        enqueue1(ctx, k0 + k, bufs1[k % 3])
+                    for _ in range(min(n, 2)):
+                        take(ctx.render_wait())
+                    torch.cuda.synchronize()
+                    return tot
+                ctx.set_option("kernel_timing", 1)
+                run1(0, warm1)
+                t1 = time.perf_counter()
+                tot1 = run1(warm1, n1)
+                dt1 = time.perf_counter() - t1
+                out["value_single_frame"] = tot1["traced"] / dt1 / 1e6
+                out["single_frame"] = {"Mrays_s": tot1["traced"] / dt1 / 1e6, "ms_per_frame": dt1 / n1 * 1e3, "frames": n1,
+                                       "rays_per_frame": tot1["traced"] / n1,
+                                       "closest_ms_per_frame": tot1["closest_ms"] / n1, "shadow_ms_per_frame": tot1["shadow_ms"] / n1,
+                                       "note": "the same camera path, one frame per set of launches on one context, two frames in flight; "
+                                               "wall clock, outside the timed region of `value`"}
+                # one of those frames against the batch path: frame 0 of the headline's last batch, rendered alone
+                if last_cams is not None:
+                    ctx.render_frames(1, [last_cams[0]], w, h, args.depth, 10, 0, 1, bufs1[0].data_ptr(), True)
+                else:
+                    ctx.render_device(w, h, args.depth, 10, bufs1[0].data_ptr())
+                torch.cuda.synchronize()
+                out["single_frame"]["frame_equals_headline_frame"] = bool(torch.equal(bufs1[0], image[:h * w * 3]))
+                del bufs1
+            except Exception as e:   # never at the expense of the headline line
+                out["single_frame"] = {"error": str(e)}
+        if default_workload and single_gpu_extras:
+            # Supplementary, outside the timed region and not `value`: frames alternating between three contexts
+            # (streams), where one frame's kernel tails overlap the next frame's kernels, and the headline's batches
+            # alternating between two contexts.
             try:
                 extra = [ctx.clone(), ctx.clone()]    # share the scene and the BVH, own stream and workspace
                 for c in extra:
@@ -607,68 +739,48 @@ def main():
                 ctx.set_option("kernel_timing", 0)
                 trio = [ctx] + extra
                 bufs = [torch.zeros(h * w * 3, dtype=torch.uint8, device=dev) for _ in range(6)]
+                path3 = synth.camera_path(flat_cam, 0, 312) if use_path else None
                 torch.cuda.synchronize()
 
-                def run1(n):      # frame by frame on one context, two frames in flight: the configuration of earlier rounds
-                    ms = [0.0, 0.0, 0]
-                    for k in range(n):
-                        if k >= 2:
-                            st1 = ctx.render_wait()
-                            ms[0] += st1.closest_ms; ms[1] += st1.shadow_ms; ms[2] += 1
-                        ctx.render_device_async(w, h, args.depth, 10, bufs[k % 3].data_ptr())
-                    for _ in range(2):
-                        ctx.render_wait()
-                    torch.cuda.synchronize()
-                    return ms
-                ctx.set_option("kernel_timing", 1)
-                run1(12)
-                t1 = time.perf_counter()
-                ms1 = run1(300)
-                dt1 = (time.perf_counter() - t1) / 300
-                ctx.set_option("kernel_timing", 0)
-                single = {"ms_per_frame": dt1 * 1e3, "Mrays_s": (total_traced / frames) / dt1 / 1e6,
-                          "closest_ms": ms1[0] / max(ms1[2], 1), "shadow_ms": ms1[1] / max(ms1[2], 1)}
-
-                def run3(n):
+                def run3(k0, n):
+                    rays = 0
                     for k in range(n):
                         if k >= 3:
-                            trio[k % 3].render_wait()
-                        trio[k % 3].render_device_async(w, h, args.depth, 10, bufs[k % 6].data_ptr())
+                            rays += trio[k % 3].render_wait().traced_rays
+                        if path3 is None:
+                            trio[k % 3].render_device_async(w, h, args.depth, 10, bufs[k % 6].data_ptr())
+                        else:
+                            trio[k % 3].render_frames_async(1, [path3[k0 + k]], w, h, args.depth, 10, 0, 1, bufs[k % 6].data_ptr(), True)
                     for k in range(n, n + 3):
-                        trio[k % 3].render_wait()
+                        rays += trio[k % 3].render_wait().traced_rays
                     torch.cuda.synchronize()
-                run3(12)
+                    return rays
+                run3(0, 12)
                 t3 = time.perf_counter()
-                run3(300)
-                dt3 = (time.perf_counter() - t3) / 300
-                out["supplementary"] = {"frame_by_frame_one_context": single,
-                                        "three_contexts_ms_per_frame": dt3 * 1e3,
-                                        "three_contexts_Mrays_s": (total_traced / frames) / dt3 / 1e6,
-                                        "frame_equals_headline_frame": bool(torch.equal(bufs[299 % 6], image[:h * w * 3]))}
+                rays3 = run3(12, 300)
+                dt3 = time.perf_counter() - t3
+                out["supplementary"] = {"three_contexts_ms_per_frame": dt3 / 300 * 1e3, "three_contexts_Mrays_s": rays3 / dt3 / 1e6}
                 if fpb > 1:
-                    # The headline's batches alternating between two contexts (streams): one batch's kernel tails and
-                    # single-workgroup kernels overlap the other batch's kernels. Not the headline because overlapping
-                    # kernels have no launch duration of their own to hold against a roofline.
                     pair = [ctx, extra[0]]
                     bufs_b = [torch.zeros(fpb * h * w * 3, dtype=torch.uint8, device=dev) for _ in range(4)]
                     torch.cuda.synchronize()
 
-                    def run2(n):
+                    def run2(k0, n):
+                        rays = 0
                         for k in range(n):
                             if k >= 2:
-                                pair[k % 2].render_wait()
-                            pair[k % 2].render_frames_async(fpb, None, w, h, args.depth, 10, 0, 1, bufs_b[k % 4].data_ptr(), True)
+                                rays += pair[k % 2].render_wait().traced_rays
+                            pair[k % 2].render_frames_async(fpb, cams_of(k0 + k), w, h, args.depth, 10, 0, 1, bufs_b[k % 4].data_ptr(), True)
                         for k in range(n, n + 2):
-                            pair[k % 2].render_wait()
+                            rays += pair[k % 2].render_wait().traced_rays
                         torch.cuda.synchronize()
-                    run2(8)
+                        return rays
+                    run2(0, 8)
                     n2 = max(300 // fpb, 8)
                     t2 = time.perf_counter()
-                    run2(n2)
-                    dt2 = (time.perf_counter() - t2) / (n2 * fpb)
-                    out["supplementary"]["batches_on_two_contexts"] = {
-                        "ms_per_frame": dt2 * 1e3, "Mrays_s": (total_traced / frames) / dt2 / 1e6,
-                        "frames_equal_headline_frames": bool(torch.equal(bufs_b[(n2 - 1) % 4], image[:fpb * h * w * 3]))}
+                    rays2 = run2(8, n2)
+                    dt2 = time.perf_counter() - t2
+                    out["supplementary"]["batches_on_two_contexts"] = {"ms_per_frame": dt2 / (n2 * fpb) * 1e3, "Mrays_s": rays2 / dt2 / 1e6}
                     del bufs_b
                 ctx.set_option("kernel_timing", 1)
                 for c in extra:
@@ -677,45 +789,51 @@ def main():
                 out["supplementary"] = {"error": str(e)}
         if default_workload and not args.no_extras:
             # The target the workload description names: the >= 1M-triangle scene at 3840x2160 (same scene, same
-            # context, outside the timed region; its own object, not `value`).
+            # context, same camera path, outside the timed region; its own object, not `value`).
             try:
                 w4, h4 = 3840, 2160
                 bufs4 = [torch.zeros(h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+                path4 = synth.camera_path(flat_cam, 0, 110) if use_path else None
                 torch.cuda.synchronize()
                 ctx.set_option("kernel_timing", 0)
 
-                def run4(n):
+                def run4(k0, n):
                     rays = 0
                     for k in range(n):
                         if k >= 1:
                             rays += ctx.render_wait().traced_rays
-                        ctx.render_device_async(w4, h4, args.depth, 10, bufs4[k % 2].data_ptr())
+                        if path4 is None:
+                            ctx.render_device_async(w4, h4, args.depth, 10, bufs4[k % 2].data_ptr())
+                        else:
+                            ctx.render_frames_async(1, [path4[k0 + k]], w4, h4, args.depth, 10, 0, 1, bufs4[k % 2].data_ptr(), True)
                     rays += ctx.render_wait().traced_rays
                     torch.cuda.synchronize()
                     return rays
-                run4(5)
+                run4(0, 5)
                 t4 = time.perf_counter()
-                rays4 = run4(100)
+                rays4 = run4(5, 100)
                 dt4 = time.perf_counter() - t4
-                out["target_4k"] = {"workload": "the same %d-triangle scene at %dx%d, depth %d, 1 GPU, 100 frames" % (flat.n_tris, w4, h4, args.depth),
+                out["target_4k"] = {"workload": "the same %d-triangle scene at %dx%d, depth %d, 1 GPU, 100 frames of the same camera path, frame by frame"
+                                                % (flat.n_tris, w4, h4, args.depth),
                                     "Mrays_s": rays4 / dt4 / 1e6, "ms_per_frame": dt4 / 100 * 1e3, "rays_per_frame": rays4 / 100}
                 del bufs4
                 try:     # two 4K frames per set of launches (as many rays as the headline's eight 1080p frames)
                     bufs4 = [torch.zeros(2 * h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
                     torch.cuda.synchronize()
 
-                    def run4b(n):
+                    def run4b(k0, n):
                         rays = 0
                         for k in range(n):
                             if k >= 1:
                                 rays += ctx.render_wait().traced_rays
-                            ctx.render_frames_async(2, None, w4, h4, args.depth, 10, 0, 1, bufs4[k % 2].data_ptr(), True)
+                            cams2 = [path4[(k0 + 2 * k) % 110], path4[(k0 + 2 * k + 1) % 110]] if path4 is not None else None
+                            ctx.render_frames_async(2, cams2, w4, h4, args.depth, 10, 0, 1, bufs4[k % 2].data_ptr(), True)
                         rays += ctx.render_wait().traced_rays
                         torch.cuda.synchronize()
                         return rays
-                    run4b(3)
+                    run4b(0, 3)
                     t4 = time.perf_counter()
-                    rays4 = run4b(50)
+                    rays4 = run4b(6, 50)
                     dt4 = time.perf_counter() - t4
                     out["target_4k"]["two_frames_per_batch"] = {"Mrays_s": rays4 / dt4 / 1e6, "ms_per_frame": dt4 / 100 * 1e3}
                     del bufs4

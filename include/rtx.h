@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 1u
+#define RTX_ABI_VERSION 2u
 
 typedef enum rtx_status {
     RTX_OK = 0,
@@ -112,6 +112,11 @@ typedef struct rtx_build_stats {
     uint32_t key_bits;       /* Morton key width used */
     float    build_ms;       /* device time of the whole build */
     float    upload_ms;      /* host->device copy of the scene arrays in rtx_scene_set */
+    uint32_t n_always;       /* triangles without an area to speak of (two edges within 1e-3 rad of parallel, or a zero edge):
+                                the reference's test answers rounding noise for them (poly.rs:149-153), no box can promise to
+                                contain that, so EVERY ray tests each of them before it enters the tree. Usually 0; a mesh with
+                                thousands of them renders correctly but slowly (rtx_last_error then holds a note after rtx_build) */
+    uint32_t reserved;
 } rtx_build_stats;
 
 /* Ray counts follow the reference's definition: one ray = one call of
@@ -140,6 +145,9 @@ typedef struct rtx_context rtx_context;
 /* ---- lifetime ------------------------------------------------------------
  * No counterpart in the reference (it has no device). */
 int  rtx_abi_version(void);
+/* 16 hex digits naming the sources this library was built from (kernels, headers, build flags): measurements quote
+ * counters only for the build they were collected on. */
+const char* rtx_source_hash(void);
 int  rtx_create(int device, rtx_context** out_ctx);
 void rtx_destroy(rtx_context* ctx);
 /* Message of the last failing call on `ctx` (or of the last failing rtx_create
@@ -158,9 +166,10 @@ const char* rtx_last_error(const rtx_context* ctx);
  *                   0: no events, a frame's launches follow each other a few microseconds closer
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
  *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
- *                   launches (default 24 = 6 units), byte 1 for shadow launches (default 10 = 2.5 units); small
+ *                   launches (default 32 = 8 units), byte 1 for shadow launches (default 10 = 2.5 units); small
  *                   launches get fewer workgroups per CU accordingly
- *   "tune2"         most traversal workgroups per CU (1..8, default 4)
+ *   "tune2"         most traversal workgroups per CU (default 6; values above the number a kernel is compiled to keep
+ *                   resident -- 4 to 6, by kernel -- change nothing)
  *   "tune3"         primitives per leaf: fixed at 1 (any other value is RTX_ERR_INVALID_ARG)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.

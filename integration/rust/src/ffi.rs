@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTX_ABI_VERSION: u32 = 1;
+pub const RTX_ABI_VERSION: u32 = 2;
 pub const RTX_OK: c_int = 0;
 pub const RTX_ERR_INVALID_ARG: c_int = 1;
 pub const RTX_ERR_NO_DEVICE: c_int = 2;
@@ -84,6 +84,8 @@ pub struct rtx_build_stats {
     pub key_bits: u32,
     pub build_ms: f32,
     pub upload_ms: f32,
+    pub n_always: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -110,6 +112,7 @@ pub enum rtx_context {}
 
 extern "C" {
     pub fn rtx_abi_version() -> c_int;
+    pub fn rtx_source_hash() -> *const c_char;
     pub fn rtx_create(device: c_int, out_ctx: *mut *mut rtx_context) -> c_int;
     pub fn rtx_destroy(ctx: *mut rtx_context);
     pub fn rtx_last_error(ctx: *const rtx_context) -> *const c_char;

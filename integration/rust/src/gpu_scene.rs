@@ -12,7 +12,9 @@ use ffi::*;
 use ray::Ray;
 use scene::intersection::Intersection;
 use scene::shapes::Primitive;
+use scene::material::{Color, Material};
 use scene::{Camera, IntersectableScene, Light, Scene, SceneIntersection};
+use vec::Vec3;
 
 pub struct GpuScene {
     ctx: *mut rtx_context,
@@ -27,9 +29,35 @@ fn check(ctx: *const rtx_context, status: i32, what: &str) {
     }
 }
 
+// The crate targets an early-2015 nightly: only `Vec::push` / `iter` / `len` / `as_ptr` are used on vectors below
+// (no `extend_from_slice`, which arrived later).
+fn push3(out: &mut Vec<f32>, vec: &Vec3) {
+    out.push(vec.x);
+    out.push(vec.y);
+    out.push(vec.z);
+}
+
+fn rgb(color: &Color) -> [f32; 3] {
+    [color.r_val(), color.g_val(), color.b_val()] // the fields r, g, b are private (src/scene/material.rs:6-10)
+}
+
+fn flat_material(mat: &Material) -> rtx_material {
+    rtx_material {
+        diffuse: rgb(&mat.diffuse),
+        ambient: rgb(&mat.ambient),
+        specular: rgb(&mat.specular),
+        emissive: rgb(&mat.emissive),
+        shininess: mat.shininess,
+        transparency: mat.transparency,
+    }
+}
+
 impl GpuScene {
     /// Flattening rules: primitive id = index in `scene.primitives` (the parser has already reversed every poly_set,
     /// src/scene/parser/mod.rs:333-338); a poly's `materials` is its de-duplicated list (parser/mod.rs:266-291).
+    /// Field names are the reference's: `Vertex.position` / `.normal` (src/scene/shapes/poly.rs:10-15),
+    /// `Sphere.origin` / `.radius` (sphere.rs:8-11), `PointLight.pos` (src/scene/mod.rs:63-66), `AreaLight.min` / `.max`
+    /// (mod.rs:78-82), `DirectionalLight.dir` (mod.rs:108-111), `Camera.*` (mod.rs:123-129).
     pub fn new(scene: Scene, device: i32, force_bvh: bool) -> GpuScene {
         let mut tri_pos: Vec<f32> = Vec::new();
         let mut tri_nrm: Vec<f32> = Vec::new();
@@ -40,46 +68,46 @@ impl GpuScene {
         let mut sph_mat: Vec<u32> = Vec::new();
         let mut sph_index: Vec<u32> = Vec::new();
         let mut materials: Vec<rtx_material> = Vec::new();
-        let mut push_material = |m: &::scene::material::Material| -> u32 {
-            materials.push(rtx_material {
-                diffuse: [m.diffuse.r_val(), m.diffuse.g_val(), m.diffuse.b_val()],
-                ambient: [m.ambient.r_val(), m.ambient.g_val(), m.ambient.b_val()],
-                specular: [m.specular.r_val(), m.specular.g_val(), m.specular.b_val()],
-                emissive: [m.emissive.r_val(), m.emissive.g_val(), m.emissive.b_val()],
-                shininess: m.shininess,
-                transparency: m.transparency,
-            });
-            (materials.len() - 1) as u32
-        };
         for (id, prim) in scene.primitives.iter().enumerate() {
             match *prim {
-                Primitive::Poly(ref p) => {
-                    for v in p.vertices.iter() {
-                        tri_pos.extend_from_slice(&[v.pos.x, v.pos.y, v.pos.z]);
-                        tri_nrm.extend_from_slice(&[v.normal.x, v.normal.y, v.normal.z]);
+                Primitive::Poly(ref poly) => {
+                    for vert in poly.vertices.iter() {
+                        push3(&mut tri_pos, &vert.position);
+                        push3(&mut tri_nrm, &vert.normal);
                     }
                     for k in 0..3 {
-                        tri_mat.push(if k < p.materials.len() { push_material(&p.materials[k]) } else { RTX_MATERIAL_NONE });
+                        if k < poly.materials.len() {
+                            materials.push(flat_material(&poly.materials[k]));
+                            tri_mat.push((materials.len() - 1) as u32);
+                        } else {
+                            tri_mat.push(RTX_MATERIAL_NONE);
+                        }
                     }
-                    tri_flags.push((if p.vertex_normal { RTX_TRI_VERTEX_NORMAL } else { 0 })
-                        | (if p.vertex_material { RTX_TRI_VERTEX_MATERIAL } else { 0 }));
+                    tri_flags.push((if poly.vertex_normal { RTX_TRI_VERTEX_NORMAL } else { 0 })
+                        | (if poly.vertex_material { RTX_TRI_VERTEX_MATERIAL } else { 0 }));
                     tri_index.push(id as u32);
                 }
-                Primitive::Sphere(ref s) => {
-                    sph.extend_from_slice(&[s.origin.x, s.origin.y, s.origin.z, s.radius]);
-                    sph_mat.push(push_material(&s.materials[0]));
+                Primitive::Sphere(ref sphere) => {
+                    push3(&mut sph, &sphere.origin);
+                    sph.push(sphere.radius);
+                    materials.push(flat_material(&sphere.materials[0]));
+                    sph_mat.push((materials.len() - 1) as u32);
                     sph_index.push(id as u32);
                 }
             }
         }
-        let lights: Vec<rtx_light> = scene.lights.iter().map(|l| match *l {
-            Light::Point(ref p) => rtx_light { type_: RTX_LIGHT_POINT, a: [p.position.x, p.position.y, p.position.z], b: [0.0; 3],
-                                               color: [p.intensity.r_val(), p.intensity.g_val(), p.intensity.b_val()] },
-            Light::Area(ref a) => rtx_light { type_: RTX_LIGHT_AREA, a: [a.min.x, a.min.y, a.min.z], b: [a.max.x, a.max.y, a.max.z],
-                                              color: [a.intensity.r_val(), a.intensity.g_val(), a.intensity.b_val()] },
-            Light::Directional(ref d) => rtx_light { type_: RTX_LIGHT_DIRECTIONAL, a: [d.direction.x, d.direction.y, d.direction.z],
-                                                     b: [0.0; 3], color: [d.intensity.r_val(), d.intensity.g_val(), d.intensity.b_val()] },
-        }).collect();
+        let mut lights: Vec<rtx_light> = Vec::new();
+        for light in scene.lights.iter() {
+            lights.push(match *light {
+                Light::Point(ref point) => rtx_light { type_: RTX_LIGHT_POINT, a: [point.pos.x, point.pos.y, point.pos.z], b: [0.0; 3],
+                                                       color: rgb(&point.intensity) },
+                Light::Area(ref area) => rtx_light { type_: RTX_LIGHT_AREA, a: [area.min.x, area.min.y, area.min.z],
+                                                     b: [area.max.x, area.max.y, area.max.z], color: rgb(&area.intensity) },
+                Light::Directional(ref directional) => rtx_light { type_: RTX_LIGHT_DIRECTIONAL,
+                                                                   a: [directional.dir.x, directional.dir.y, directional.dir.z],
+                                                                   b: [0.0; 3], color: rgb(&directional.intensity) },
+            });
+        }
         let cam = &scene.camera;
         let desc = rtx_scene_desc {
             n_tris: tri_index.len() as u32,
@@ -120,12 +148,16 @@ impl GpuScene {
     pub fn intersect_batch(&self, rays: &[Ray]) -> Vec<(i32, f32)> {
         let mut ori = Vec::with_capacity(rays.len() * 3);
         let mut dir = Vec::with_capacity(rays.len() * 3);
-        for r in rays {
-            ori.extend_from_slice(&[r.ori.x, r.ori.y, r.ori.z]);
-            dir.extend_from_slice(&[r.dir.x, r.dir.y, r.dir.z]);
+        for ray in rays.iter() {
+            push3(&mut ori, &ray.ori);
+            push3(&mut dir, &ray.dir);
         }
-        let mut prim = vec![-1i32; rays.len()];
-        let mut t = vec![0f32; rays.len()];
+        let mut prim: Vec<i32> = Vec::with_capacity(rays.len());
+        let mut t: Vec<f32> = Vec::with_capacity(rays.len());
+        for _ in 0..rays.len() {
+            prim.push(-1);
+            t.push(0.0);
+        }
         check(self.ctx, unsafe { rtx_intersect_batch(self.ctx, rays.len() as u64, ori.as_ptr(), dir.as_ptr(),
                                                       prim.as_mut_ptr(), t.as_mut_ptr()) }, "rtx_intersect_batch");
         prim.into_iter().zip(t.into_iter()).collect()
@@ -133,7 +165,11 @@ impl GpuScene {
 
     /// The whole frame: what the loop of `RayTracer::trace_rays` (src/lib.rs:262-271) produces, row 0 = top row.
     pub fn render(&self, width: u32, height: u32, depth: usize, num_samples: usize) -> (Image, rtx_render_stats) {
-        let mut rgb = vec![0u8; (width as usize) * (height as usize) * 3];
+        let n_bytes = (width as usize) * (height as usize) * 3;
+        let mut rgb: Vec<u8> = Vec::with_capacity(n_bytes);
+        for _ in 0..n_bytes {
+            rgb.push(0);
+        }
         let mut stats = rtx_render_stats::default();
         check(self.ctx, unsafe { rtx_render(self.ctx, width, height, depth as u32, num_samples as u32, rgb.as_mut_ptr(), &mut stats) },
               "rtx_render");

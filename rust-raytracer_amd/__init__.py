@@ -31,7 +31,7 @@ TILE = 8
 
 # Every symbol include/rtx.h declares; tests check that the library exports all of them.
 EXPORTED_SYMBOLS = [
-    "rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
+    "rtx_abi_version", "rtx_source_hash", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_set_option", "rtx_scene_set", "rtx_build",
     "rtx_intersect_batch", "rtx_intersect_batch_device", "rtx_intersect_batch_exhaustive", "rtx_primary_hits",
     "rtx_render", "rtx_render_device", "rtx_render_tiles", "rtx_tiles_per_rank", "rtx_assemble_tiles", "rtx_stream",
     "rtx_debug_stamps", "rtx_render_device_async", "rtx_render_tiles_async", "rtx_render_wait", "rtx_assemble_tiles_async",
@@ -72,7 +72,8 @@ class SceneDesc(C.Structure):
 
 class BuildStats(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
-                ("uses_bvh", C.c_uint32), ("key_bits", C.c_uint32), ("build_ms", C.c_float), ("upload_ms", C.c_float)]
+                ("uses_bvh", C.c_uint32), ("key_bits", C.c_uint32), ("build_ms", C.c_float), ("upload_ms", C.c_float),
+                ("n_always", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -130,6 +131,7 @@ def lib():
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         vp, u32, u64, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64
         L.rtx_abi_version.restype = C.c_int
+        L.rtx_source_hash.restype = C.c_char_p
         L.rtx_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.rtx_destroy.argtypes = [vp]
         L.rtx_destroy.restype = None
@@ -170,6 +172,11 @@ def lib():
         L.rtx_debug_stamps.restype = u64
         _lib = L
     return _lib
+
+
+def source_hash():
+    """Names the sources the LOADED library was built from (rtx_source_hash)."""
+    return lib().rtx_source_hash().decode()
 
 
 def host_lib():

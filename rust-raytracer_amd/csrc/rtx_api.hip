@@ -82,6 +82,11 @@ extern "C" {
 
 int rtx_abi_version(void) { return (int)RTX_ABI_VERSION; }
 
+#ifndef RTX_SOURCE_HASH
+#define RTX_SOURCE_HASH "unknown"
+#endif
+const char* rtx_source_hash(void) { return RTX_SOURCE_HASH; }
+
 const char* rtx_last_error(const rtx_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int rtx_create(int device, rtx_context** out_ctx) {
@@ -358,7 +363,11 @@ int rtx_clone(rtx_context* src, rtx_context** out_ctx) {
     ctx->opt_cost_order = src->opt_cost_order;
     ctx->trav_spill_need = src->trav_spill_need;
     if (src->built) {
-        RTX_HIP(src, hipStreamSynchronize(src->stream));   // the tree the clone reads is complete
+        const hipError_t se = hipStreamSynchronize(src->stream);   // the tree the clone reads is complete
+        if (se != hipSuccess) {
+            rtx_destroy(ctx);
+            return rtx_fail(src, RTX_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
+        }
         rc = rtx_alloc_traversal_scratch(ctx);
         if (rc != RTX_OK) {
             rtx_fail(src, rc, ctx->error);

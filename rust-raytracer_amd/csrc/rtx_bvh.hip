@@ -1042,6 +1042,7 @@ int rtx_bvh_build(rtx_context* ctx) {
             hipLaunchKernelGGL(k_copy_recs, dim3((flat_count + kThreads - 1) / kThreads), dim3(kThreads), 0, st, recs, flat, flat_count, always);
             s.always = always;
             s.n_always = flat_count;
+            bs.n_always = flat_count;
         }
         bs.n_nodes = (uint32_t)n_nodes;
         bs.n_leaves = (uint32_t)n_leaves;
@@ -1092,5 +1093,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     ctx->build_store = store;
     ctx->build_stats = bs;
     ctx->built = true;
+    if (bs.n_always > 64)   // correct, but every ray pays for each of them: say so where a caller who wonders will look
+        ctx->error = "note: " + std::to_string(bs.n_always) + " triangles without an area are tested by every ray (rtx_build_stats.n_always)";
     return RTX_OK;
 }

@@ -152,6 +152,9 @@ struct rtx_context {
     uint32_t comm_rank = 0, comm_world = 0;
     void* gather_buf = nullptr;
     size_t gather_size = 0;
+    void* comm_status = nullptr;   // one device word: the root tells the senders whether it can receive (rtx_gather_frames)
+    uint32_t gather_agreed_root = 0xFFFFFFFFu;   // (root, bytes) every rank knows the root's gather buffer to be good for
+    size_t gather_agreed_size = 0;
     // render workspace (grown on demand)
     std::vector<void*> work_allocs;
     uint64_t work_batch = 0;      // pixels per batch the workspace was sized for

@@ -174,7 +174,7 @@ RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4)
         frame = (uint32_t)g / pg.rays_per_frame;
         gl = (uint32_t)g - frame * pg.rays_per_frame;
     }
-    const CamSetup& cam = (pg.frames > 1) ? pg.cams[frame] : pg.cam;
+    const CamSetup& cam = pg.cams ? pg.cams[frame] : pg.cam;   // cams: cameras handed in by the caller (device array); else the scene's
     const uint64_t tile = (gl >> 6) * pg.world + pg.rank;
     const uint32_t lane = (uint32_t)(gl & 63);
     const uint32_t x = (uint32_t)(tile % pg.tiles_x) * RTX_TILE + (lane & 7u);
@@ -1465,22 +1465,20 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         ctx->shade_a_resident = (uint32_t)per_cu;
     }
 
-    const CamSetup cam = make_cam(cameras ? cameras[0] : ctx->camera, w, h);
+    // Cameras handed in by the caller travel through a pinned page into a small device array that the level-0 kernels
+    // read (one page per frame in flight), never through kernel arguments: a recorded launch sequence (below) then
+    // serves every batch of the same shape, whatever its cameras -- a camera path replays one recording.
+    const CamSetup cam = make_cam(ctx->camera, w, h);
     const CamSetup* d_cams = nullptr;
-    uint64_t cam_hash = 0;   // recorded launch sequences hold the cameras they were recorded with
-    if (n_frames > 1) {
-        if (rays_local > batch || rays_local >= (1ull << 32))
-            return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "the frames of a batch must fit one ray batch (fewer frames, or a larger batch_pixels)");
+    if (n_frames > 1 && (rays_local > batch || rays_local >= (1ull << 32)))
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "the frames of a batch must fit one ray batch (fewer frames, or a larger batch_pixels)");
+    if (n_frames > 1 || cameras) {
         if (!ctx->cam_dev) RTX_HIP(ctx, hipMalloc(&ctx->cam_dev, 3 * 4096));
         const int page = slot ? 1 + async_slot : 0;
         CamSetup* host_cams = (CamSetup*)((char*)ctx->pinned + (size_t)(4 + page) * 4096);
+        // (page 0 belongs to the synchronous calls, which end with a wait for the stream: its last copy has run)
         for (uint32_t f = 0; f < n_frames; ++f) host_cams[f] = make_cam(cameras ? cameras[f] : ctx->camera, w, h);
         d_cams = (const CamSetup*)((char*)ctx->cam_dev + (size_t)page * 4096);
-        cam_hash = 1469598103934665603ull;
-        for (size_t k = 0; k < sizeof(CamSetup) * n_frames; ++k) cam_hash = (cam_hash ^ ((const uint8_t*)host_cams)[k]) * 1099511628211ull;
-    } else if (cameras) {
-        cam_hash = 1469598103934665603ull;
-        for (size_t k = 0; k < sizeof(CamSetup); ++k) cam_hash = (cam_hash ^ ((const uint8_t*)&cam)[k]) * 1099511628211ull;
     }
     const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
     const bool any_shadow = !s.has_transparent;
@@ -1518,7 +1516,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                                  ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(s))) << 32) |
                                      trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
                                                  shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s))),
-                                 (uint64_t)(uintptr_t)wk.ctl ^ (cam_hash * 0x9e3779b97f4a7c15ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
+                                 (uint64_t)(uintptr_t)wk.ctl ^ (d_cams ? 0x9e3779b97f4a7c15ull : 0ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;
         if (fg) {

@@ -33,7 +33,10 @@ int main(int argc, char** argv) {
         if (f == "-h" || f == "--help") {
             std::printf("Usage: %s [options]\n\nOptions:\n"
                         "    -h --help           Print this help menu\n"
-                        "    -b --bvh            Optimize scene intersection with BVH-tree (always on above 16 primitives; the image is the same)\n"
+                        "    -b --bvh            Optimize scene intersection with BVH-tree. Here the GPU tree is used above 16 primitives\n"
+                        "                        whether or not -b is given, and -b also builds it for smaller scenes. The image never\n"
+                        "                        depends on -b: both paths return the hits of the reference's exhaustive loop (lowest\n"
+                        "                        index wins ties), not those of the reference's own -b tree, whose tie rule differs\n"
                         "    -s --size -s 500    The width and height of the image to be generated\n"
                         "    -a --arealight-samples -a 1000\n                        The number of times to sample the area lights\n"
                         "    -d --depth -d 10    The depth of the recursion in the main loop\n"

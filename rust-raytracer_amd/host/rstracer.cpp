@@ -225,7 +225,9 @@ std::vector<Poly> SceneParser::parse_polyset() {   // parser/mod.rs:236-298
     expect("numPolys");
     long np = next_int();
     std::vector<Poly> set;
-    if (np > 0) set.reserve((size_t)np);
+    // the count is only a hint for the allocation: a file cannot hold more polys than it has bytes for (a poly is at
+    // least 16 bytes of text), whatever its header claims
+    if (np > 0) set.reserve(std::min<size_t>((size_t)np, (size_ - pos_) / 16 + 1));
     auto mat = [&](uint32_t i) -> const Material& {
         if (i >= materials.size()) throw Error("index out of bounds: the len is " + std::to_string(materials.size()) + " but the index is " + std::to_string(i));
         return materials[i];
@@ -390,11 +392,12 @@ void SceneParser::flat_polyset(FlatScene& f, uint32_t& n_prims) {
     expect("numPolys");
     long np = next_int();
     const size_t first = f.tri_flags.size();
-    if (np > 0) {
-        f.tri_pos.reserve(f.tri_pos.size() + (size_t)np * 9);
-        f.tri_normals.reserve(f.tri_normals.size() + (size_t)np * 9);
-        f.tri_mat.reserve(f.tri_mat.size() + (size_t)np * 3);
-        f.tri_flags.reserve(first + (size_t)np);
+    if (np > 0) {   // a hint only: bounded by what the rest of the file can hold (a poly is at least 16 bytes of text)
+        const size_t hint = std::min<size_t>((size_t)np, (size_ - pos_) / 16 + 1);
+        f.tri_pos.reserve(f.tri_pos.size() + hint * 9);
+        f.tri_normals.reserve(f.tri_normals.size() + hint * 9);
+        f.tri_mat.reserve(f.tri_mat.size() + hint * 3);
+        f.tri_flags.reserve(first + hint);
     }
     const uint8_t flags = (uint8_t)((vertex_normal ? RTX_TRI_VERTEX_NORMAL : 0) | (vertex_material ? RTX_TRI_VERTEX_MATERIAL : 0));
     for (; np > 0; --np) {
@@ -619,8 +622,10 @@ Image Image::load(const std::string& path) {
     const uint32_t off = le(10, 4);
     img.width = le(18, 4);
     img.height = le(22, 4);
-    const uint32_t row = (img.width * 3 + 3) & ~3u;
-    if (buf.size() < (size_t)off + (size_t)row * img.height) throw Error("truncated BMP: " + path);
+    const uint64_t row = ((uint64_t)img.width * 3 + 3) & ~(uint64_t)3;      // 64-bit: a header may claim any width
+    if (img.width == 0 || img.height == 0 || img.width > (1u << 24) || img.height > (1u << 24) || off < 54 || off > buf.size() ||
+        row * img.height > buf.size() - off)
+        throw Error("truncated BMP: " + path);
     img.rgb.resize((size_t)img.width * img.height * 3);
     for (uint32_t y = 0; y < img.height; ++y)
         for (uint32_t x = 0; x < img.width; ++x) {

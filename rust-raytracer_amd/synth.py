@@ -110,6 +110,33 @@ def heightfield_scene(n, spec=0.0, glass_lattice=0, small_spheres=0, seed=SEED):
     return f
 
 
+def camera_path(flat, first, count, step=0.004):
+    """`count` cameras of a fly-around of the height field, frames first .. first + count - 1 of the path: frame k looks
+    at the origin from the scene camera's position turned by k * step radians about the y axis, bobbing by a few percent
+    of its height (period 483 frames, so that no two frames of an orbit coincide). Frame 0 is the scene's own camera.
+    All arithmetic in float64, rounded once to the f32 fields of rtx_camera: every rank computes the same cameras."""
+    p0 = np.array([flat.camera.pos[k] for k in range(3)], np.float64)
+    cams = []
+    for k in range(first, first + count):
+        a = k * step
+        ca, sa = math.cos(a), math.sin(a)
+        pos = np.array([ca * p0[0] + sa * p0[2], p0[1] * (1.0 + 0.04 * math.sin(2.0 * math.pi * k / 483.0)), -sa * p0[0] + ca * p0[2]])
+        view = -pos / np.linalg.norm(pos)
+        c = _pkg.Camera()
+        for i in range(3):
+            c.pos[i] = float(np.float32(pos[i]))
+            c.view_dir[i] = float(np.float32(view[i]))
+            c.ortho_up[i] = flat.camera.ortho_up[i]
+        c.focal_dist = flat.camera.focal_dist
+        c.vertical_fov = flat.camera.vertical_fov
+        if k == 0:      # exactly the scene's camera
+            for i in range(3):
+                c.pos[i] = flat.camera.pos[i]
+                c.view_dir[i] = flat.camera.view_dir[i]
+        cams.append(c)
+    return cams
+
+
 MATERIAL_NONE = _pkg.MATERIAL_NONE
 LIGHT_POINT = _pkg.LIGHT_POINT
 

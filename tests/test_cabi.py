@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(rtx):
 
 
 def test_abi_version(rtx):
-    assert rtx.lib().rtx_abi_version() == 1
+    assert rtx.lib().rtx_abi_version() == 2
 
 
 def test_struct_sizes_match_header(rtx):

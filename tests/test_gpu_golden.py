@@ -42,3 +42,36 @@ def test_cli_writes_the_same_bmp(rtx, golden, tmp_path):
     img = np.frombuffer(data[off:off + row * h], np.uint8).reshape(h, row)[:, :w * 3].reshape(h, w, 3)[::-1, :, ::-1]
     diff = np.abs(img.astype(int) - golden["test04_rgb"].astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999
+
+
+def _read_bmp(path):
+    data = open(path, "rb").read()
+    assert data[:2] == b"BM"
+    w, h = int.from_bytes(data[18:22], "little"), int.from_bytes(data[22:26], "little")
+    off = int.from_bytes(data[10:14], "little")
+    row = (w * 3 + 3) & ~3
+    return np.frombuffer(data[off:off + row * h], np.uint8).reshape(h, row)[:, :w * 3].reshape(h, w, 3)[::-1, :, ::-1]
+
+
+@pytest.mark.parametrize("name", ["test02", "test01", "test09"])
+def test_cli_bvh_flag_leaves_the_image_unchanged(rtx, golden, tmp_path, name):
+    """`-b` (src/main.rs:46,70-74). The reference switches to its median-split tree, whose tie rule differs
+    (bvh.rs:134); here `-b` only forces the device tree for scenes of at most 16 primitives (test02: 7, test01: 13)
+    and changes nothing for larger ones (test09): with and without the flag the image is the golden frame of the
+    exhaustive loop, byte for byte between the two runs."""
+    import subprocess
+    from conftest import ROOT
+    plain, forced = tmp_path / "plain", tmp_path / "forced"
+    subprocess.check_call([rtx.CLI_PATH, "-i", name, "-s", "100", "-d", "10", "-o", str(plain)], cwd=ROOT)
+    subprocess.check_call([rtx.CLI_PATH, "-b", "-i", name, "-s", "100", "-d", "10", "-o", str(forced)], cwd=ROOT)
+    a, b = _read_bmp(str(plain) + ".bmp"), _read_bmp(str(forced) + ".bmp")
+    assert np.array_equal(a, b)
+    diff = np.abs(b.astype(int) - golden[name + "_rgb"].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
+
+
+def test_cli_help_says_what_bvh_does_here(rtx):
+    import subprocess
+    from conftest import ROOT
+    text = subprocess.check_output([rtx.CLI_PATH, "--help"], cwd=ROOT).decode()
+    assert "-b --bvh" in text and "The image never depends on -b" in " ".join(text.split())
