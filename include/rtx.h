@@ -164,11 +164,11 @@ const char* rtx_last_error(const rtx_context* ctx);
  *                   buffer and in-flight slot; at most 32 are kept, so cycle through a few output buffers, not many); 0: always plain launches
  *   "kernel_timing" 1 (default): the traversal launches carry timing events (closest_ms, shadow_ms of the statistics);
  *                   0: no events, a frame's launches follow each other a few microseconds closer
- *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default 48; 0 = never)
+ *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default RTX_DEFAULT_TUNE0 = 48; 0 = never)
  *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
- *                   launches (default 32 = 8 units), byte 1 for shadow launches (default 10 = 2.5 units); small
+ *                   launches (default 32 = 8 units), byte 1 for shadow launches (default 10 = 2.5 units), RTX_DEFAULT_TUNE1; small
  *                   launches get fewer workgroups per CU accordingly
- *   "tune2"         most traversal workgroups per CU (default 6; values above the number a kernel is compiled to keep
+ *   "tune2"         most traversal workgroups per CU (default RTX_DEFAULT_TUNE2 = 6; values above the number a kernel is compiled to keep
  *                   resident -- 4 to 6, by kernel -- change nothing)
  *   "tune3"         primitives per leaf: fixed at 1 (any other value is RTX_ERR_INVALID_ARG)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
@@ -177,6 +177,11 @@ const char* rtx_last_error(const rtx_context* ctx);
  *                   (RTX_ERR_HIP) when one differs from what the one-launch bottom-up refit handed over (tests; default 0)
  *   "stamps"        1 = traversal kernels record per-wavefront time stamps (see rtx_debug_stamps); at the next rtx_build */
 int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
+/* The defaults of "tune0" .. "tune2", in one place: the library initialises its options from these, and tests and
+ * tools that restore a default read them here. */
+#define RTX_DEFAULT_TUNE0 48
+#define RTX_DEFAULT_TUNE1 (32 + (10 << 8)) /* 8 units per closest-hit wavefront, 2.5 per shadow wavefront */
+#define RTX_DEFAULT_TUNE2 6
 
 /* ---- scene ---------------------------------------------------------------
  * Replaces RayTracer::set_scene (src/lib.rs:64-67): copies the flattened scene

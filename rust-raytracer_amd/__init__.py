@@ -42,6 +42,19 @@ EXPORTED_SYMBOLS = [
 MAX_BATCH_FRAMES = 64
 
 
+def _header_defaults():
+    """RTX_DEFAULT_TUNE* of include/rtx.h (the one place the defaults are written down)."""
+    import re
+    text = open(os.path.join(os.path.dirname(_HERE), "include", "rtx.h")).read()
+    out = {}
+    for name, expr in re.findall(r"#define\s+(RTX_DEFAULT_TUNE\d)\s+([^/\n]+)", text):
+        out[name] = int(eval(expr, {"__builtins__": {}}))      # integer arithmetic only: "48", "(32 + (10 << 8))"
+    return out
+
+
+DEFAULT_TUNE = _header_defaults()
+
+
 class RtxError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))

@@ -173,7 +173,7 @@ struct rtx_context {
     int64_t opt_batch_pixels = 1 << 24;
     int64_t opt_pool_factor = 4;  // retained shading nodes per batch pixel
     uint32_t num_cus = 256;
-    int32_t opt_tune[4] = {48, 32 + (10 << 8), 6, RTX_LEAF_MAX};
+    int32_t opt_tune[4] = {RTX_DEFAULT_TUNE0, RTX_DEFAULT_TUNE1, RTX_DEFAULT_TUNE2, RTX_LEAF_MAX};
     void* build_arena = nullptr;        // temporaries of rtx_build, kept for the next build when small
     size_t build_arena_size = 0;
     bool hit_fraction_known = false;   // a frame of the current scene has been collected

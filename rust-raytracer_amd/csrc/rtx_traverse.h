@@ -10,7 +10,10 @@
 // the ray-side padding below covers rounding in the primitive tests, which
 // grows with the magnitude of the ray origin.
 //
-// Two differences are documented rather than reproduced. A primitive test that
+// Three differences are documented rather than reproduced. A sphere test that returns Hit(-0.0) (a quotient that
+// underflows, sphere.rs:82,99-101; the loop's `new_t < t` treats it as 0.0) is reported as Hit(+0.0): the same number,
+// ordered the same way against every other hit, but with ONE bit pattern, so that the order-independent rule can be
+// evaluated on the bits (the 64-bit minimum of rtx_coop.h) as well as on the values. A primitive test that
 // returns Hit(NaN) (only possible for rays with non-finite components,
 // sphere.rs:70-102) is ignored here, while the reference would keep it if it
 // came first. And a ray that lies IN the plane of a triangle -- direction and
@@ -50,8 +53,10 @@ RTX_D float u2f(uint32_t u) { return __uint_as_float(u); }
 // a triangle-only scene pays neither the kind test nor, in the node step, the sphere widening).
 template <bool SPH = true>
 RTX_D bool record_hit(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float& t) {
-    if (!SPH || f2u(q1.w) == 0u) return tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);
-    return sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
+    if (!SPH || f2u(q1.w) == 0u) return tri_intersect(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z), &t);   // t > 1e-7 on a hit
+    const bool hit = sphere_intersect(o, d, v3(q0.x, q0.y, q0.z), q1.x, &t);
+    t += 0.0f;   // -0.0 -> +0.0 (a sphere hit is >= 0 by value; the sign of a zero must not order it after every positive t)
+    return hit;
 }
 // One candidate primitive against one ray; updates (best_t, best_id).
 template <bool SPH = true>

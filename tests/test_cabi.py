@@ -33,7 +33,7 @@ def test_struct_sizes_match_header(rtx):
     assert C.sizeof(rtx.Material) == 56
     assert C.sizeof(rtx.Light) == 40
     assert C.sizeof(rtx.Camera) == 44
-    assert C.sizeof(rtx.BuildStats) == 32
+    assert C.sizeof(rtx.BuildStats) == 40
     assert C.sizeof(rtx.RenderStats) == 7 * 8 + 3 * 4 + 5 * 4
 
 

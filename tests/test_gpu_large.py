@@ -13,6 +13,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import rtx_amd as _rtx      # noqa: E402  (the defaults the library starts with, from include/rtx.h)
+DEFAULT_TUNE1, DEFAULT_TUNE2 = _rtx.DEFAULT_TUNE["RTX_DEFAULT_TUNE1"], _rtx.DEFAULT_TUNE["RTX_DEFAULT_TUNE2"]
+
 
 def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -219,16 +222,16 @@ def test_launch_sizing_does_not_change_the_frame(big):
     ctx.set_option("tune1", 1 + (1 << 8))      # a quarter unit per wavefront: every launch takes the largest grid
     refs = [ctx.render(w, h, 10, 10) for w, h in sizes]
     try:
-        for t1, t2 in ((24 + (10 << 8), 4), (255 + (255 << 8), 4), (24 + (10 << 8), 1), (4 + (4 << 8), 8)):
+        for t1, t2 in ((DEFAULT_TUNE1, DEFAULT_TUNE2), (255 + (255 << 8), 4), (24 + (10 << 8), 1), (4 + (4 << 8), 8)):
             ctx.set_option("tune1", t1)
             ctx.set_option("tune2", t2)
             for (w, h), (ref, sr) in zip(sizes, refs):
                 img, st = ctx.render(w, h, 10, 10)
                 assert np.array_equal(img, ref), (t1, t2, w, h)
                 assert (st.shadow_rays, st.shaded_nodes) == (sr.shadow_rays, sr.shaded_nodes)
-    finally:
-        ctx.set_option("tune1", 24 + (10 << 8))
-        ctx.set_option("tune2", 4)
+    finally:      # the library's defaults (rtx_internal.h, opt_tune): later tests share this context
+        ctx.set_option("tune1", DEFAULT_TUNE1)
+        ctx.set_option("tune2", DEFAULT_TUNE2)
 
 
 def test_recorded_frames_replay_exactly(big, rtx):
@@ -475,3 +478,89 @@ def test_ray_tree_larger_than_the_node_pool_is_rendered_in_smaller_batches(rtx, 
         (rs["shadow_rays"], rs["reflect_rays"], rs["last_level_rays"], rs["shaded_nodes"])
     diff = np.abs(big.astype(int) - ref["rgb"].astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999
+
+
+def test_sphere_hit_at_minus_zero_wins_in_every_visiting_order(rtx, orc):
+    """Sphere::intersects can return Hit(-0.0) (a quotient that underflows, sphere.rs:82,99-101); the loop's `new_t < t`
+    (src/scene/mod.rs:188-196) orders it as 0.0, i.e. before every positive t. These rays do produce it (found by
+    searching the f32 arithmetic): the hit must win over farther spheres in the one-ray-per-lane phase and in the
+    cooperative phase (forced with tune0 = 65: the 64-bit minimum works on bit patterns, where -0.0 would sort last),
+    through the tree and through the exhaustive kernel, and equal the CPU oracle's id. The device reports the t of
+    such a hit as +0.0 (documented difference: same value, one bit pattern)."""
+    cases = [((0.001281233155168593, 0.00035370339173823595, 0.0006943055777810514),
+              (-5.342120062468926e-19, -4.187189087924039e-18, 3.217797516509363e-18), 0.001499574864283204),
+             ((-89.75702667236328, -198.0777130126953, 134.1038360595703),
+              (-2147655312474112.0, 5.386509182461542e+16, -1304850524536832.0), 255.48960876464844),
+             ((24.598154067993164, 98.12321472167969, 183.2332305908203),
+              (2.0669234618250035e+17, -4.0198344397973094e+17, -7.992927953103094e+17), 209.3025665283203)]
+    for o, d, r in cases:
+        o32, d32 = np.asarray(o, np.float32), np.asarray(d, np.float32)
+        u = d32.astype(np.float64) / np.linalg.norm(d32.astype(np.float64))
+        flat = rtx.FlatScene()
+        mat = flat.add_material((0.5, 0.5, 0.5))
+        rng = np.random.default_rng(5)
+        spheres = [(0.0, 0.0, 0.0, r)]                       # the sphere the ray starts on (hit at -0.0)
+        for k in range(1, 24):                               # further spheres strung along the ray: hits at t > 0
+            c = o32.astype(np.float64) + u * (3.0 * r * k) + rng.normal(size=3) * 0.05 * r
+            spheres.append((c[0], c[1], c[2], 0.6 * r))
+        order = rng.permutation(len(spheres))                # the near sphere is not primitive 0
+        flat.sph_center_radius = np.asarray(spheres, np.float32)[order]
+        flat.sph_mat = np.full((len(spheres),), mat, np.uint32)
+        flat.add_light(rtx.LIGHT_POINT, (0.0, 10.0 * r, 0.0))
+        flat.set_camera((0.0, 0.0, 5.0 * r), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), 0.7)
+        want = int(np.where(order == 0)[0][0])
+        n = 64
+        ori = np.tile(o32, (n, 1))
+        dirs = np.tile(d32, (n, 1))
+        ref_p, ref_t = orc.OracleScene.from_flat(flat).intersect_batch(ori[:1], dirs[:1])
+        assert ref_p[0] == want and ref_t[0] == 0.0 and np.signbit(ref_t[0]), (ref_p, ref_t)
+        for tune0 in (48, 65, 0):
+            with rtx.Context(0) as ctx:
+                ctx.set_option("force_mode", 2)
+                ctx.set_option("tune0", tune0)
+                ctx.set_scene(flat)
+                ctx.build()
+                assert ctx.build_stats["uses_bvh"] == 1
+                pb, tb = ctx.intersect_batch(ori, dirs)
+                px, tx = ctx.intersect_batch(ori, dirs, exhaustive=True)
+            assert (pb == want).all() and (px == want).all(), (tune0, pb[:4], px[:4], want)
+            assert (tb == 0.0).all() and (tx == 0.0).all()
+            assert not np.signbit(tb).any() and not np.signbit(tx).any()      # one bit pattern for zero
+
+
+def test_hundreds_of_triangles_without_area(rtx, synth):
+    """Triangles whose edges are parallel (or zero) answer rounding noise in the reference's test (poly.rs:149-153), so
+    every ray tests each of them before it enters the tree. A mesh with hundreds of them: the build reports how many
+    (rtx_build_stats.n_always, and a note in rtx_last_error above 64), and the tree still equals the exhaustive loop."""
+    flat = synth.heightfield_scene(64)
+    rng = np.random.default_rng(31)
+    k = 300
+    a = rng.uniform(-1.0, 1.0, (k, 3))
+    e = rng.normal(size=(k, 3)) * rng.uniform(0.01, 0.5, (k, 1))
+    needles = np.stack([a, a + e, a + e * rng.uniform(1.5, 3.0, (k, 1))], axis=1)       # three points on one line
+    needles[::5, 2] = needles[::5, 1]                                                  # a zero edge
+    needles[::7] *= 100.0                                                              # large coordinates: louder noise
+    n0 = flat.n_tris
+    flat.tri_pos = np.concatenate([flat.tri_pos, needles.astype(np.float32)])
+    flat.tri_mat = np.concatenate([flat.tri_mat, np.tile(flat.tri_mat[:1], (k, 1))])
+    flat.tri_flags = np.concatenate([flat.tri_flags, np.zeros((k,), np.uint8)])
+    n = 40000
+    ori = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    ori[:, 1] = np.abs(ori[:, 1]) + 0.3
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 2, 1] = -np.abs(d[: n // 2, 1])
+    d[::4] *= 50.0
+    with rtx.Context(0) as ctx:
+        ctx.set_option("verify_build", 1)
+        ctx.set_scene(flat)
+        st = ctx.build()
+        assert st["uses_bvh"] == 1 and st["n_prims"] == n0 + k
+        assert k * 0.9 <= st["n_always"] <= k, st
+        note = ctx._L.rtx_last_error(ctx._h).decode()
+        assert "tested by every ray" in note and str(st["n_always"]) in note
+        pb, tb = ctx.intersect_batch(ori, d)
+        px, tx = ctx.intersect_batch(ori, d, exhaustive=True)
+    assert np.array_equal(pb, px), "%d of %d rays differ" % ((pb != px).sum(), n)
+    hit = px >= 0
+    assert hit.mean() > 0.2
+    assert np.array_equal(_bits(tb)[hit], _bits(tx)[hit])

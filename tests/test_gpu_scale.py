@@ -18,9 +18,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 CONFIGS = {
-    4: dict(grid=2829, spec=0.3, glass=8, spheres=0, w=3840, h=2160, depth=5, n_tris=16006482, n_spheres=64, oracle_stride=(420, 400)),
+    4: dict(grid=2829, spec=0.3, glass=8, spheres=0, w=3840, h=2160, depth=5, n_tris=16006482, n_spheres=64, oracle_stride=(280, 260)),
     5: dict(grid=5600, spec=0.3, glass=0, spheres=1280000, w=7680, h=4320, depth=5, n_tris=62720000, n_spheres=1280000,
-            oracle_stride=(1100, 900)),
+            oracle_stride=(560, 500)),
 }
 
 
@@ -139,7 +139,8 @@ def test_frame_reproducible_ray_counts_and_two_shards(scene, rtx):
 
 
 def test_full_size_frame_against_oracle_pixels(scene, orc):
-    """A few dozen pixels of the full-size frame through the CPU oracle's exhaustive loop (16 threads)."""
+    """126 pixels of the full-size frame through the CPU oracle's exhaustive loop (16 threads); at least 20 of them
+    must be shaded pixels (most of the frame is sky), so that ids, t and RGB at full size rest on more than a handful."""
     n_cfg, cfg, flat, ctx = scene
     w, h, depth = cfg["w"], cfg["h"], cfg["depth"]
     sx, sy = cfg["oracle_stride"]
@@ -154,7 +155,7 @@ def test_full_size_frame_against_oracle_pixels(scene, orc):
     sub = (slice(0, h, sy), slice(0, w, sx))
     assert np.array_equal(prim[sub], ref["prim_id"][sub])
     hit = ref["prim_id"][sub] >= 0
-    assert hit.sum() >= 3
+    assert hit.sum() >= 20, int(hit.sum())
     assert np.array_equal(_bits(t[sub])[hit], _bits(ref["t"][sub])[hit])
     diff = np.abs(rgb[sub].astype(int) - ref["rgb"][sub].astype(int)).max(axis=2)
     assert (diff <= 1).all()

@@ -88,7 +88,6 @@ def test_clone_shares_scene_and_tree(rtx):
     parent = rtx.Context(0)
     parent.set_scene(flat)
     parent.build()
-    free_before = torch.cuda.mem_get_info()[0]
     clone = parent.clone()
     w, h = 320, 200
     a = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
@@ -115,7 +114,44 @@ def test_clone_shares_scene_and_tree(rtx):
     assert torch.equal(a, b)
     clone.close()
     del a, b
-    assert free_before > 0
+
+
+def test_clone_costs_less_memory_than_a_second_scene(rtx):
+    """rtx_clone shares the scene arrays and the tree: what a clone adds to the device's memory is its own traversal
+    scratch (and, at its first frame, its workspace), not a second copy of the scene and a second tree."""
+    torch = pytest.importorskip("torch")
+    synth = importlib.import_module("rust-raytracer_amd.synth")
+    flat = synth.heightfield_scene(500)                    # 499 000 triangles: arrays + records + nodes + shading records ~ 100 MB
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def free():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    parent = rtx.Context(0)
+    parent.set_scene(flat)
+    parent.build()
+    f1 = free()
+    clone = parent.clone()
+    f2 = free()
+    second = rtx.Context(0)                                # what a caller without rtx_clone would do
+    second.set_scene(flat)
+    second.build()
+    f3 = free()
+    clone_cost, second_cost = f1 - f2, f2 - f3
+    scene_bytes = flat.n_tris * (36 + 12 + 1 + 4 + 64 + 48)      # positions, material ids, flags, prim_ref, shading record, traversal record
+    assert second_cost >= scene_bytes, (second_cost, scene_bytes)
+    assert clone_cost >= 0 and clone_cost + scene_bytes <= second_cost, (clone_cost, second_cost, scene_bytes)
+    # and the clone works on the shared tree
+    rays = np.random.default_rng(3).normal(size=(256, 3)).astype(np.float32)
+    rays[:, 1] = -np.abs(rays[:, 1]) - 0.3
+    ori = np.tile(np.array([0.0, 1.0, 0.0], np.float32), (256, 1))
+    pa, ta = parent.intersect_batch(ori, rays)
+    pb, tb = clone.intersect_batch(ori, rays)
+    assert np.array_equal(pa, pb) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32)) and (pa >= 0).any()
+    for c in (second, clone, parent):
+        c.close()
 
 
 def test_host_buffer_calls_stop_allocating(rtx, gpu_ctx_factory):

@@ -75,3 +75,30 @@ def test_noalloc_small_scene_and_limits(rtx, gpu_ctx_factory):
     with pytest.raises(rtx.RtxError) as e:
         ctx.intersect_batch_device_noalloc(1, 1, 1, 1, (1 << 26) + 1)
     assert e.value.status == 6 and "RTX_NOALLOC_MAX_RAYS" in str(e.value)
+
+
+def test_noalloc_calls_leave_free_device_memory_unchanged(rtx, gpu_ctx_factory):
+    """What the entry point is for: a call allocates and frees nothing and does not wait for the device. Free device
+    memory is the same before and after a run of calls (the first call of the process has already happened above: code
+    objects and the static array are loaded), and a call returns while its kernel is still running behind a long one."""
+    torch = pytest.importorskip("torch")
+    synth = importlib.import_module("rust-raytracer_amd.synth")
+    flat = synth.heightfield_scene(224, glass_lattice=4)
+    ctx = gpu_ctx_factory(flat)
+    rng = np.random.default_rng(29)
+    n = 200000
+    ori, d = _rays(flat, rng, n)
+    dev = torch.device("cuda", 0)
+    d_o, d_d = torch.from_numpy(ori).to(dev), torch.from_numpy(d).to(dev)
+    p = torch.empty((n,), dtype=torch.int32, device=dev)
+    t = torch.empty((n,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.intersect_batch_device_noalloc(d_o.data_ptr(), d_d.data_ptr(), p.data_ptr(), t.data_ptr(), n)     # warm
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(6):
+        ctx.intersect_batch_device_noalloc(d_o.data_ptr(), d_d.data_ptr(), p.data_ptr(), t.data_ptr(), n if k % 2 == 0 else n // 3)
+    free_enqueued = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    assert free_enqueued == free0 and torch.cuda.mem_get_info()[0] == free0
+    assert int((p >= 0).sum()) > 0
