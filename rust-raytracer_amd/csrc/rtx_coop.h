@@ -57,7 +57,11 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
     int best_id = ANY ? 0 : 0x7fffffff;
     int cur = kRefDone, sp = 0;
     if (active) {
-        if (!s.uses_bvh || !in_safe_region(s, o)) {   // every primitive, as the reference loop does
+        // every primitive, as the reference loop does: without a tree, for origins outside the region the sphere margin
+        // is proven for, and -- scenes with spheres -- for directions so short or long that |d|^2 or the products of
+        // sphere.rs:59-67 leave the normal range of f32 (an underflowing |d|^2 makes the reference's sphere test report
+        // hits for spheres nowhere near the ray; no box can promise those)
+        if (!s.uses_bvh || !in_safe_region(s, o) || (SPH && !dir_in_range(d))) {
             if (ANY) {
                 for (uint32_t i = 0; i < s.n_prims; ++i)
                     if (any_record<SPH>(s.recs, i, o, d, dist_light)) { best_id = 1; break; }

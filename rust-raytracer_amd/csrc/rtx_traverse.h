@@ -35,11 +35,12 @@
 // spills 28-120 bytes per lane and is slower, except where noted). The kernels are compiled for exactly this many
 // waves, their LDS (stacks 16 KiB + shared slots 3 KiB + the copy of the tree's top levels) is sized to fit it, and
 // launches ask for no more workgroups per CU than that (more would queue behind the others and end the launch late).
-//   closest hit:           triangle-only 74 registers -> 6; with spheres 103 -> 5 (28 bytes of scratch, still -1..-6 %)
-//   any-hit shadow rays:   triangle-only 79-82 -> 6; with spheres, point lights 109 -> 5 (config 5: -4 %), area lights 112 -> 4
-//   closest-hit shadow rays (transparent materials): triangle-only 89-95 -> 5; with spheres 118-124 -> 4
-constexpr int closest_waves(bool sph) { return sph ? 5 : 6; }
-constexpr int shadow_waves(bool any, bool area, bool sph) { return sph ? ((any && !area) ? 5 : 4) : (any ? 6 : 5); }
+//   closest hit:           triangle-only 74 registers, with spheres 76-77 -> 6 (80 registers is the limit for six)
+//   any-hit shadow rays:   triangle-only 75-78, with spheres 76-79 -> 6
+//   closest-hit shadow rays (transparent materials): triangle-only 88, with spheres 95-96 -> 5
+// (tools/kernel_resources.sh prints the compiler's figures: none of them uses scratch.)
+constexpr int closest_waves(bool sph) { return 6; }
+constexpr int shadow_waves(bool any, bool area, bool sph) { return any ? 6 : 5; }
 #define RTX_WAVES_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // Which kernels a scene runs on: the triangle-only ones unless it holds spheres or triangles that every ray has to test
 // (DevScene::always; rare enough to share the general kernels, compiled once more with that loop).
@@ -151,6 +152,12 @@ RTX_D bool in_safe_region(const DevScene& s, V3 o) {
            fabsf(o.z - s.safe_c[2]) <= s.safe_r;  // false for NaN origins
 }
 
+// |d|^2 within 2^-40 .. 2^40 (false for NaN): see coop_trace.
+RTX_D bool dir_in_range(V3 d) {
+    const float a = vdot(d, d);
+    return a >= 0x1p-40f && a <= 0x1p40f;
+}
+
 // Per-lane traversal stack. The first RTX_STACK_LDS entries live in LDS: entry k of
 // lane l at lds[k * RTX_BLOCK + l], so the lanes of a wavefront always touch 64
 // consecutive dwords (conflict-free whatever their individual depths are). Deeper
@@ -188,26 +195,35 @@ struct TravStack {
     }
 };
 
-// Sphere tests accept rays that miss: the discriminant b*b - 4ac (sphere.rs:62-67) is a
-// difference of two numbers near 4|d|^2 D^2 (D = distance from the ray origin to the
-// centre), each carrying a few roundings, so a ray passing within sqrt(r^2 + K D^2) of the
-// centre can still report a hit (worst case of the f32 operations: K = 16 * 2^-24; the
-// constant below adds a margin). The excess over r depends on the ray, so it is not baked
-// into the boxes: a node whose subtree holds spheres is flagged and stores, per child, the
-// smallest sphere radius below it (f16, rounded down); the traversal widens such a child by
-//     e = K Dn^2 / (sqrt(rmin^2 + K Dn^2) + rmin),   Dn = distance to the node's farthest corner,
-// which bounds sqrt(r^2 + K D^2) - r for every sphere in the child (decreasing in r,
-// increasing in D). Children without spheres store +inf and get e = 0.
+// Sphere tests accept rays that miss: the discriminant b*b - 4ac (sphere.rs:62-67) is a difference of two numbers near
+// 4|d|^2 D^2 (D = distance from the ray origin to the centre), each carrying a few roundings, so a ray passing within
+// sqrt(r^2 + K D^2) of the centre can still report a hit. K follows from the reference's operation order, u = 2^-24,
+// o = fl(ori - centre) taken as the (slightly moved, by <= u D per axis) exact offset, D = |o|, a = |d|^2:
+//   fl(d.o): three products, two sums: error <= 3u |d| D, so b = 2 fl(d.o) is off by <= 6u |d| D and, with |b| <= 2|d|D,
+//            fl(b*b) by <= 2 |b| 6u|d|D + u b^2 <= 28u a D^2;
+//   c = fl(fl(o.o) - fl(r*r)): <= 3u D^2 + u r^2 + u (D^2 - r^2) = 4u D^2;  a = fl(d.d): relative 3u;
+//   fl(fl(4a) c): <= 4a (4u c + 4u D^2) <= 32u a D^2 (c <= D^2);  the final subtraction keeps the sign.
+// Exactly, b*b - 4ac = 4a (r^2 - p^2), p = distance of the centre from the ray's line: a non-negative computed value
+// needs p^2 <= r^2 + 15u D^2. K = 15.5 * 2^-24 leaves room for the second-order terms and the moved offset; boxes are
+// padded, quantised outwards and the margin below is scaled by 1.002 on top. (|d|^2 and the products must stay in the
+// normal range of f32 for this: see dir_in_range.)
+// The excess over r depends on the ray, so it is not baked into the boxes: a node with a sphere somewhere below it is
+// flagged, and the traversal widens ALL its children by
+//     e = sqrt(K) Dn  >=  sqrt(r^2 + K Dn^2) - r   for every r > 0,     Dn = distance to the node's farthest corner,
+// one square root per node step (a per-child margin from the smallest radius below each child -- still stored in the node --
+// cost a square root and a reciprocal per child, 75 instructions per step more, and bought little: the margin only tightens
+// for spheres with r^2 >~ K D^2, and for those it is small against r either way). Children without spheres are widened
+// too, which is harmless (a box may always be larger).
 #ifndef RTX_SPHERE_K
-#define RTX_SPHERE_K 1.25e-6f   // 21 * 2^-24
+#define RTX_SPHERE_K 9.2387e-7f   // 15.5 * 2^-24
 #endif
 constexpr float kSphereK = RTX_SPHERE_K;
+constexpr float kSphereSqrtK = 9.6119e-4f * 1.002f;   // sqrt(K), rounded up, with the margin
 
 // wn* / wf*: the four children's near and far plane bytes of one axis; ln* / lf*: the matching offsets.
-template <bool WIDEN>
 RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, uint32_t wfy, uint32_t wfz, uint32_t nchild,
-                       const RayBox& rb, float limit, float sx, float sy, float sz, float lnx, float lny, float lnz, float lfx,
-                       float lfy, float lfz, const float* e, float* t, int* hits = nullptr) {
+                       float limit, float sx, float sy, float sz, float lnx, float lny, float lnz, float lfx,
+                       float lfy, float lfz, float* t, int* hits = nullptr) {
     const float inf = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -215,11 +231,6 @@ RTX_D void node4_slabs(uint32_t wnx, uint32_t wny, uint32_t wnz, uint32_t wfx, u
         float nx = __builtin_fmaf((float)((wnx >> sh) & 0xffu), sx, lnx), fx = __builtin_fmaf((float)((wfx >> sh) & 0xffu), sx, lfx);
         float ny = __builtin_fmaf((float)((wny >> sh) & 0xffu), sy, lny), fy = __builtin_fmaf((float)((wfy >> sh) & 0xffu), sy, lfy);
         float nz = __builtin_fmaf((float)((wnz >> sh) & 0xffu), sz, lnz), fz = __builtin_fmaf((float)((wfz >> sh) & 0xffu), sz, lfz);
-        if (WIDEN) {   // planes move outward by e: e * |1/d| in ray parameter
-            const float wx = e[k] * fabsf(rb.inv.x), wy = e[k] * fabsf(rb.inv.y), wz = e[k] * fabsf(rb.inv.z);
-            nx -= wx; ny -= wy; nz -= wz;
-            fx += wx; fy += wy; fz += wz;
-        }
         // [lo, hi] = the ray's parameter range inside the box, cut to [0, limit]: one comparison decides
         const float lo = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
         const float hi = fminf(fminf(fminf(fx, fy), fz), limit);
@@ -262,28 +273,22 @@ RTX_D int node4_step(const uint4 A, const uint4 B, const uint4 C, const uint4 D,
     float t[4];
     int hk[4] = {0, 0, 0, 0};   // SORT = false: which children the ray enters (a range that starts at +inf counts: visiting more is always safe)
     int r[4] = {(int)C.z, (int)C.w, (int)D.x, (int)D.y};
-    // spheres below: widen their children (see kSphereK). The branch is taken by the whole wavefront or not at all
+    // spheres below: widen the children (see kSphereK). The branch is taken by the whole wavefront or not at all
     // (a vote), so that wavefronts away from any sphere skip the widening arithmetic instead of computing it masked.
+    float lnx_ = lnx, lny_ = lny, lnz_ = lnz, lfx_ = lfx, lfy_ = lfy, lfz_ = lfz;
     if (SPH && __ballot((meta >> 31) != 0u) != 0ull) {
         const float dx = fmaxf(fabsf(ox - o.x), fabsf(__builtin_fmaf(255.0f, stx, ox) - o.x));
         const float dy = fmaxf(fabsf(oy - o.y), fabsf(__builtin_fmaf(255.0f, sty, oy) - o.y));
         const float dz = fmaxf(fabsf(oz - o.z), fabsf(__builtin_fmaf(255.0f, stz, oz) - o.z));
-        const float kd2 = kSphereK * (dx * dx + dy * dy + dz * dz);
-        float e[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t hbits = (((k < 2) ? D.z : D.w) >> (16 * (k & 1))) & 0xffffu;
-            const unsigned short hs = (unsigned short)hbits;
-            _Float16 hf;
-            __builtin_memcpy(&hf, &hs, 2);
-            const float rq = fminf((float)hf, 65504.0f);             // +inf (no sphere) -> finite, masked below
-            const float den = __builtin_amdgcn_sqrtf(__builtin_fmaf(rq, rq, kd2)) + rq + 1e-30f;
-            e[k] = ((meta >> 31) != 0u && hbits != 0x7c00u) ? kd2 * __builtin_amdgcn_rcpf(den) * 1.002f : 0.0f;
-        }
-        node4_slabs<true>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, e, t, SORT ? nullptr : hk);
-    } else {
-        node4_slabs<false>(wnx, wny, wnz, wfx, wfy, wfz, nchild, rb, limit, sx, sy, sz, lnx, lny, lnz, lfx, lfy, lfz, nullptr, t, SORT ? nullptr : hk);
+        const float dn2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        // v_sqrt_f32 is good to 1 ulp; the 1.002 in kSphereSqrtK covers it
+        const float e = ((meta >> 31) != 0u) ? kSphereSqrtK * __builtin_amdgcn_sqrtf(dn2) : 0.0f;
+        // planes move outward by e: e * |1/d| in ray parameter
+        const float wx = e * fabsf(rb.inv.x), wy = e * fabsf(rb.inv.y), wz = e * fabsf(rb.inv.z);
+        lnx_ -= wx; lny_ -= wy; lnz_ -= wz;
+        lfx_ += wx; lfy_ += wy; lfz_ += wz;
     }
+    node4_slabs(wnx, wny, wnz, wfx, wfy, wfz, nchild, limit, sx, sy, sz, lnx_, lny_, lnz_, lfx_, lfy_, lfz_, t, SORT ? nullptr : hk);
 #define RTX_CE(i, j)                                   \
     do {                                               \
         const bool sw = t[j] < t[i];                   \
