@@ -203,9 +203,10 @@ def main():
                          "configuration (so that a rank's share of a batch is as much work as eight whole frames), 2 per GPU for "
                          "config 4, 1 for config 5 and with --scaling strong")
     ap.add_argument("--lib", type=str, default="", help="another build of the library (file name in rust-raytracer_amd/; experiments)")
-    ap.add_argument("--cameras", type=str, default="path", choices=("path", "fixed"),
+    ap.add_argument("--cameras", type=str, default="path", choices=("path", "fixed", "same"),
                     help="path (default): every frame has its own camera, frame k of a fly-around of the scene (synth.camera_path); "
-                         "fixed: the scene's camera for every frame (the frames of a batch are then copies of one frame)")
+                         "fixed: the scene's camera for every frame (the frames of a batch are then copies of one frame); "
+                         "same: like fixed, but handed over as one explicit camera per frame (experiments: the cost of the camera array)")
     ap.add_argument("--scaling", type=str, default="weak", choices=("weak", "strong"),
                     help="weak (default): a step is --frames-per-step x N frames, rendered in batches, so the work per GPU does not depend on N; "
                          "strong: a step is --frames-per-step frames whatever N is, one frame per set of launches, each frame cut into N shares")
@@ -440,11 +441,11 @@ def main():
     path_cache = {}
 
     def cams_of(k):
+        if args.cameras == "same":
+            return path_cache.setdefault(0, synth.camera_path(flat_cam, 0, 1) * fpb)
         if not use_path:
             return None
         if k not in path_cache:
-            if len(path_cache) > 4096:
-                path_cache.clear()
             path_cache[k] = synth.camera_path(flat_cam, k * fpb, fpb)
         return path_cache[k]
 
@@ -484,6 +485,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_path:      # the path is computed before anything is timed: the loop only hands cameras over
+        n_batches_total = (args.warmup + args.steps) * fps // fpb + 3 * ring + 16
+        for k in range(n_batches_total):
+            cams_of(k)
     reset_acc()
     if multi and not gloo:      # set-up, like the BVH build: every (context, slab) pair renders once plainly and is recorded once
         for _ in range(3 * ring):

@@ -135,8 +135,15 @@ RTX_D bool block_sees_overflow(const Ctl* ctl) {
     return s_overflow != 0;
 }
 
+// Up to kCamsByValue cameras of a frame or batch travel as arguments of its first kernel (a copy from pinned memory
+// costs a stream that renders one small frame after the other 20-40 us per frame: a hand-over to the copy engine and back).
+constexpr uint32_t kCamsByValue = 8;
+struct CamBlock {
+    CamSetup cam[kCamsByValue];
+};
 // first: the first batch of a frame starts the frame's counters from zero.
-__global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback, int first) {
+__global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback, int first, CamSetup* cams_dst, uint32_t n_cams, CamBlock cams) {
+    for (uint32_t k = 0; k < n_cams; ++k) cams_dst[k] = cams.cam[k];
     for (int k = 0; k < 7; ++k) {
         if (first) ctl->stat[k] = 0;
         if (rollback) ctl->stat[k] = ctl->saved[k];
@@ -166,15 +173,7 @@ struct PrimaryGen {
     uint32_t frames, rays_per_frame;
     const CamSetup* cams;
 };
-RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4) {
-    const uint64_t g = pg.first + i;
-    uint64_t gl = g;
-    uint32_t frame = 0;
-    if (pg.frames > 1) {   // first == 0 and g < 2^32 (checked by the host)
-        frame = (uint32_t)g / pg.rays_per_frame;
-        gl = (uint32_t)g - frame * pg.rays_per_frame;
-    }
-    const CamSetup& cam = pg.cams ? pg.cams[frame] : pg.cam;   // cams: cameras handed in by the caller (device array); else the scene's
+RTX_D void primary_ray_of(const CamSetup& cam, const PrimaryGen& pg, uint64_t g, uint64_t gl, float4& o4, float4& d4) {
     const uint64_t tile = (gl >> 6) * pg.world + pg.rank;
     const uint32_t lane = (uint32_t)(gl & 63);
     const uint32_t x = (uint32_t)(tile % pg.tiles_x) * RTX_TILE + (lane & 7u);
@@ -184,6 +183,35 @@ RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4)
     if (valid) d = compute_ray_dir(cam, (float)x, (float)(cam.h - y - 1));   // lib.rs:263
     o4 = make_float4(cam.cam_pos.x, cam.cam_pos.y, cam.cam_pos.z, u2f((uint32_t)g));
     d4 = make_float4(d.x, d.y, d.z, u2f(valid ? (RTX_RAY_VALID | RTX_RAY_VACUUM) : 0u));
+}
+// lds_cams: the workgroup's copy of pg.cams in LDS, or nullptr (the traversal kernel asks for a camera per work unit,
+// and most units of a frame with sky in it are done after a step or two: the camera's latency is a large part of them).
+// Three separate calls, so that each reads its camera from one known address space (kernel arguments, LDS, memory).
+// CAMS = false: the caller knows that there is no camera array (one frame, camera in the kernel arguments): the
+// traversal kernel is compiled once that way, because the mere possibility of an array costs its per-unit set-up a
+// quarter of the launch (the camera then lives in registers picked from three sources instead of in scalar operands).
+template <bool CAMS = true>
+RTX_D void primary_ray(const PrimaryGen& pg, uint32_t i, float4& o4, float4& d4, const CamSetup* lds_cams = nullptr) {
+    const uint64_t g = pg.first + i;
+    uint64_t gl = g;
+    uint32_t frame = 0;
+    if (pg.frames > 1) {   // first == 0 and g < 2^32 (checked by the host)
+        frame = (uint32_t)g / pg.rays_per_frame;
+        gl = (uint32_t)g - frame * pg.rays_per_frame;
+    }
+    // A wavefront's 64 rays belong to one frame (rays_per_frame is a multiple of 64): the index is uniform.
+    frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
+    if (!CAMS) {
+        primary_ray_of(pg.cam, pg, g, gl, o4, d4);
+        return;
+    }
+    // (the camera is copied into registers first: handing the core a reference would make the compiler keep one
+    // pointer for the three sources, and a pointer to a kernel argument puts the whole argument block into scratch)
+    CamSetup cam;
+    if (lds_cams) cam = lds_cams[frame];
+    else if (pg.cams) cam = pg.cams[frame];   // cameras handed in by the caller (device array)
+    else cam = pg.cam;                        // one frame: its camera is a kernel argument
+    primary_ray_of(cam, pg, g, gl, o4, d4);
 }
 // The same rays written to queue 0 (rtx_primary_hits reads them back).
 __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(PrimaryGen pg, Work wk, uint32_t n) {
@@ -232,6 +260,7 @@ struct UnitOrder {
 struct UnitQueue {
     uint32_t* heads;        // [8][32]
     uint32_t n_units, n_groups, per_shard, shard, probe;
+    uint32_t n_pos = 0, n_ordered = 0;   // sorted positions to hand out (the larger of the two group counts); groups the order knows
     uint32_t res_k = 0, res_n = 0, fine = 0xffffffffu;   // COARSE: next position of the current shard's counter that this wavefront holds, how many it holds
     const uint32_t* order;  // sorted position -> group, or nullptr
     UnitOrder* uo;
@@ -243,7 +272,19 @@ struct UnitQueue {
         shard = blockIdx.x & 7u;
         probe = 0;
         uo = uo_;
-        order = (uo && n_units > 0 && uo->n_order == n_units) ? uo->order() : nullptr;
+        // The order of the previous launch serves this one when it has the same number of units -- or nearly the same:
+        // the shadow launch of the next frame of a moving camera has a few units more or fewer (its units follow the
+        // hits), and its costs still lie where they lay. The order is a permutation of the groups it knew; groups past
+        // those go out at the end in index order, groups it knew that no longer exist are skipped.
+        order = nullptr;
+        if (uo && n_units > 0 && uo->n_order > 0) {
+            n_ordered = (uo->n_order + kGroup - 1) >> kGroupLog2;
+            const uint32_t lo_g = min(n_groups, n_ordered), hi_g = max(n_groups, n_ordered);
+            if (n_ordered <= uo->cap && hi_g - lo_g <= (hi_g >> 3)) {
+                order = uo->order();
+                n_pos = hi_g;
+            }
+        }
         fine = order ? uo->fine_units : 0xffffffffu;
     }
     // Called once per launch by every wavefront after init (only one thread writes).
@@ -278,10 +319,11 @@ struct UnitQueue {
                         }
                     }
                     const uint32_t gpos = (k >> kGroupLog2) * 8u + sh;
-                    if (gpos < n_groups) {
-                        const uint32_t u = order[gpos] * kGroup + (k & (kGroup - 1u));
+                    if (gpos < n_pos) {
+                        const uint32_t g = gpos < n_ordered ? order[gpos] : gpos;   // beyond what the order knew: the group itself
+                        const uint32_t u = g * kGroup + (k & (kGroup - 1u));
                         if (u < n_units) { unit = u; break; }
-                        continue;   // past the end of the last, partial group
+                        continue;   // a group that no longer exists, or past the end of the last, partial group
                     }
                     if (COARSE) res_k = res_n = 0;   // this shard is empty: the next one starts one unit at a time
                 } else {
@@ -423,7 +465,7 @@ static_assert(RTX_BLOCK * kShadeItems == 64 << kChunkUnitsLog2, "a chunk of k_sh
 
 // Closest hit for every ray of a queue (Scene::intersects, scene/mod.rs:181-201):
 // one ray per lane (variant 0, the default).
-template <bool SPH, bool ALWAYS = false>
+template <bool SPH, bool ALWAYS = false, bool CAMS = false>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void k_trace_queue(DevScene s, RayQueue q, Ctl* ctl, int qi, PrimaryGen pg, UnitOrder* uo, uint32_t* chunk_cnt,
                                                                                                                     unsigned long long* hit_mask) {
     __shared__ int lds[RTX_STACK_LDS * RTX_BLOCK];
@@ -432,8 +474,15 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void 
     __shared__ uint4 top_lds[kTop * 4];
     TravStack st;
     st.set(lds, s);
+    // the cameras of a batch of frames, once per workgroup (up to kCamLds of them; more are read from memory per unit)
+    constexpr uint32_t kCamLds = CAMS ? 16 : 1;
+    __shared__ CamSetup cam_lds[kCamLds];
+    const bool cams_in_lds = CAMS && pg.enabled && pg.cams && pg.frames <= kCamLds;
+    if (CAMS && cams_in_lds)
+        for (uint32_t k = threadIdx.x; k < pg.frames * (uint32_t)(sizeof(CamSetup) / 4); k += RTX_BLOCK)
+            reinterpret_cast<uint32_t*>(cam_lds)[k] = reinterpret_cast<const uint32_t*>(pg.cams)[k];
     TopCache tc;
-    tc.load(top_lds, s, kTop);
+    tc.load(top_lds, s, kTop);   // ends with a workgroup barrier
     if (ctl->overflow) return;   // the batch is being abandoned
     const uint32_t n = ctl->n_rays[qi];
     WaveStamp ws;
@@ -453,7 +502,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_WAVES_ATTR(closest_waves(SPH)) void 
         float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = o4;
         if (i < n) {
             if (pg.enabled) {
-                primary_ray(pg, i, o4, d4);
+                primary_ray<CAMS>(pg, i, o4, d4, cams_in_lds ? cam_lds : nullptr);
             } else {
                 o4 = q.o[i];
                 d4 = q.d[i];
@@ -1312,16 +1361,21 @@ void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_u
     const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(ctx->ds)))), block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
     unsigned long long* masks = shade ? wk.hit_mask : nullptr;
+    // one binary per (spheres, always-tested triangles, camera array): see primary_ray
+#define RTX_LAUNCH_CLOSEST(SPH_, ALW_, CAMS_)                                                                                              \
+    do {                                                                                                                                    \
+        if (t0 || t1) hipExtLaunchKernelGGL((k_trace_queue<SPH_, ALW_, CAMS_>), grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks); \
+        else hipLaunchKernelGGL((k_trace_queue<SPH_, ALW_, CAMS_>), grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);   \
+    } while (0)
+    const bool cams = pg.enabled && pg.cams != nullptr;
     if (ctx->ds.n_always) {
-        if (t0 || t1) hipExtLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
-        else hipLaunchKernelGGL((k_trace_queue<true, true>), grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        if (cams) RTX_LAUNCH_CLOSEST(true, true, true); else RTX_LAUNCH_CLOSEST(true, true, false);
     } else if (ctx->ds.n_spheres) {
-        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
-        else hipLaunchKernelGGL(k_trace_queue<true>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        if (cams) RTX_LAUNCH_CLOSEST(true, false, true); else RTX_LAUNCH_CLOSEST(true, false, false);
     } else {
-        if (t0 || t1) hipExtLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, t0, t1, 0, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
-        else hipLaunchKernelGGL(k_trace_queue<false>, grid, block, 0, st, ctx->ds, wk.q[qi], wk.ctl, qi, pg, uo, counts, masks);
+        if (cams) RTX_LAUNCH_CLOSEST(false, false, true); else RTX_LAUNCH_CLOSEST(false, false, false);
     }
+#undef RTX_LAUNCH_CLOSEST
     if (shade) hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kScanThreads), 0, st, wk.ctl, qi, wk.chunk_cnt, wk.chunk_base);
 }
 template <bool ANY, bool AREA>
@@ -1465,14 +1519,19 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         ctx->shade_a_resident = (uint32_t)per_cu;
     }
 
-    // Cameras handed in by the caller travel through a pinned page into a small device array that the level-0 kernels
-    // read (one page per frame in flight), never through kernel arguments: a recorded launch sequence (below) then
-    // serves every batch of the same shape, whatever its cameras -- a camera path replays one recording.
-    const CamSetup cam = make_cam(ctx->camera, w, h);
+    // One frame: its camera is an argument of the level-0 kernels (the scene's, or the caller's). A batch of frames: the
+    // cameras travel through a pinned page into a small device array that the level-0 kernels read (one page per frame
+    // in flight). A RECORDED launch sequence (below) bakes kernel arguments in, so a frame that can be recorded takes
+    // the array as well when the caller hands in a camera: a camera path then replays one recording instead of
+    // recording every frame.
+    const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
+    const bool graphable = slot && ctx->opt_graphs && !ctx->opt_kernel_timing && ctx->hit_fraction_known && single_level && rays_local > 0 &&
+                           rays_local <= batch;
+    const CamSetup cam = make_cam((cameras && n_frames == 1) ? cameras[0] : ctx->camera, w, h);
     const CamSetup* d_cams = nullptr;
     if (n_frames > 1 && (rays_local > batch || rays_local >= (1ull << 32)))
         return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "the frames of a batch must fit one ray batch (fewer frames, or a larger batch_pixels)");
-    if (n_frames > 1 || cameras) {
+    if (n_frames > 1 || (cameras && graphable)) {
         if (!ctx->cam_dev) RTX_HIP(ctx, hipMalloc(&ctx->cam_dev, 3 * 4096));
         const int page = slot ? 1 + async_slot : 0;
         CamSetup* host_cams = (CamSetup*)((char*)ctx->pinned + (size_t)(4 + page) * 4096);
@@ -1480,7 +1539,6 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         for (uint32_t f = 0; f < n_frames; ++f) host_cams[f] = make_cam(cameras ? cameras[f] : ctx->camera, w, h);
         d_cams = (const CamSetup*)((char*)ctx->cam_dev + (size_t)page * 4096);
     }
-    const bool single_level = levels == 1;   // k_shade_b writes the pixels, no backward pass
     const bool any_shadow = !s.has_transparent;
     EventPool ev{slot ? &slot->events : &ctx->events};
     hipEvent_t f0 = ev.next(), f1 = ev.next();
@@ -1491,8 +1549,6 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     // recorded once as a graph and replayed afterwards.
     // (not with kernel timing: events recorded by a graph cannot be read back as times)
     // (and not before a frame has told how large the shadow launch should be)
-    const bool graphable = slot && ctx->opt_graphs && !ctx->opt_kernel_timing && ctx->hit_fraction_known && single_level && rays_local > 0 &&
-                           rays_local <= batch;
     rtx_context::FrameGraph* fg = nullptr;
     struct CaptureGuard {   // a stream must not be left in capture mode on an error path
         hipStream_t st;
@@ -1543,7 +1599,15 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     if (!recording) RTX_HIP(ctx, hipEventRecord(f0, st));
     if (clear_first)
         RTX_HIP(ctx, hipMemsetAsync(d_rgb_tiles, 0, (direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3) * n_frames, st));
-    if (d_cams) {
+    // The cameras reach the device array inside the first kernel's arguments when they are few and the launches are
+    // not being recorded (a recording must read the cameras of the batch it is replayed for: a copy from the pinned
+    // page, whose contents are those of replay time); otherwise as that copy.
+    const bool cams_by_value = d_cams && n_frames <= kCamsByValue && !graphable;
+    CamBlock cam_block{};
+    if (cams_by_value) {
+        const int page = slot ? 1 + async_slot : 0;
+        std::memcpy(cam_block.cam, (char*)ctx->pinned + (size_t)(4 + page) * 4096, sizeof(CamSetup) * n_frames);
+    } else if (d_cams) {
         const int page = slot ? 1 + async_slot : 0;
         RTX_HIP(ctx, hipMemcpyAsync((void*)d_cams, (char*)ctx->pinned + (size_t)(4 + page) * 4096, sizeof(CamSetup) * n_frames, hipMemcpyHostToDevice, st));
     }
@@ -1553,7 +1617,8 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     for (uint64_t first = 0; first < rays_local;) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(cur_batch, rays_local - first);
         ++n_batches;
-        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback, n_batches == 1 ? 1 : 0);
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback, n_batches == 1 ? 1 : 0, (CamSetup*)d_cams,
+                           (cams_by_value && n_batches == 1) ? n_frames : 0u, cam_block);
         rollback = 0;
         const PrimaryGen gen{cam, first, rank, world, tiles_x, (uint32_t)n_tiles, 1u, n_frames, (uint32_t)rays_per_frame, d_cams};   // level 0: rays come from their index
         PrimaryGen no_gen = gen;
@@ -1741,7 +1806,7 @@ int rtx_primary_impl(rtx_context* ctx, uint32_t w, uint32_t h, int32_t* d_prim, 
     const CamSetup cam = make_cam(ctx->camera, w, h);
     for (uint64_t first = 0; first < rays; first += batch) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(batch, rays - first);
-        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0, 1);
+        hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, 0, 1, (CamSetup*)nullptr, 0u, CamBlock{});
         const PrimaryGen gen{cam, first, 0u, 1u, tiles_x, (uint32_t)n_tiles, 1u};
         hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 1u << 22)), dim3(RTX_BLOCK), 0, st, gen, wk, n);   // k_primary_out reads the directions
         launch_closest(ctx, wk, 0, n, gen, nullptr, false, st);
