@@ -173,6 +173,10 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "tune3"         primitives per leaf: fixed at 1 (any other value is RTX_ERR_INVALID_ARG)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.
+ *   "level_hints"   1 (default) = a frame whose ray tree has several levels (reflective or transparent materials) enqueues as many
+ *                   levels as the previous frame of the same shape used, plus one, without asking the device in between (one
+ *                   wait per frame instead of one per level; such frames stay in flight behind the _async entry points), and is
+ *                   rendered again level by level when its tree turned out deeper; 0 = always level by level. Never changes results.
  *   "verify_build"  1 = rtx_build recomputes, in a launch of its own, every inner node's box from its children's and fails
  *                   (RTX_ERR_HIP) when one differs from what the one-launch bottom-up refit handed over (tests; default 0)
  *   "stamps"        1 = traversal kernels record per-wavefront time stamps (see rtx_debug_stamps); at the next rtx_build */

@@ -174,6 +174,8 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value) {
         ctx->opt_graphs = value ? 1 : 0;
     } else if (k == "kernel_timing") {
         ctx->opt_kernel_timing = value ? 1 : 0;
+    } else if (k == "level_hints") {
+        ctx->opt_level_hints = value ? 1 : 0;
     } else if (k == "cost_order") {
         ctx->opt_cost_order = value ? 1 : 0;
     } else if (k == "verify_build") {
@@ -361,6 +363,7 @@ int rtx_clone(rtx_context* src, rtx_context** out_ctx) {
     ctx->opt_graphs = src->opt_graphs;
     ctx->opt_kernel_timing = src->opt_kernel_timing;
     ctx->opt_cost_order = src->opt_cost_order;
+    ctx->opt_level_hints = src->opt_level_hints;
     ctx->trav_spill_need = src->trav_spill_need;
     if (src->built) {
         const hipError_t se = hipStreamSynchronize(src->stream);   // the tree the clone reads is complete

@@ -124,7 +124,7 @@ __device__ __forceinline__ uint64_t spread21(uint64_t x) {  // bit i -> bit 3i
 // along its thin axis, which would interleave splits that separate nothing a ray cares about. The bounds are read
 // from device memory (k_bounds of the same stream), so the host does not wait for them.
 __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                                                      const SceneBounds* __restrict__ sb, int bits, uint64_t* __restrict__ keys,
+                                                      const SceneBounds* __restrict__ sb, int bits, int split_kinds, uint64_t* __restrict__ keys,
                                                       uint32_t* __restrict__ vals) {
     float cmin[3], max_ext = 0.0f;
 #pragma unroll
@@ -143,7 +143,13 @@ __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* _
         const float qx = fminf(fmaxf((cx - cmin[0]) * scale, 0.0f), qmax);
         const float qy = fminf(fmaxf((cy - cmin[1]) * scale, 0.0f), qmax);
         const float qz = fminf(fmaxf((cz - cmin[2]) * scale, 0.0f), qmax);
-        keys[id] = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
+        uint64_t key = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
+        // split_kinds (a scene with triangles AND spheres): spheres sort after all triangles, so that the hierarchy's top
+        // split separates the kinds and a node below it holds one kind only -- the traversal widens the children of nodes
+        // with spheres under them (rtx_traverse.h), which must not happen to the small triangles of a dense mesh.
+        // (bmin.w carries a sphere's radius and +inf for a triangle.)
+        if (split_kinds && a.w < __builtin_inff()) key |= 1ull << (3 * bits);
+        keys[id] = key;
         vals[id] = id;
     }
 }
@@ -613,11 +619,13 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, uint32_t level, const
             float cmn[4][3], cmx[4][3];
             uint32_t rcode[4] = {0x7c00u, 0x7c00u, 0x7c00u, 0x7c00u};   // smallest sphere radius per child, f16; +inf = none
             bool spheres = false;
+            uint32_t sphere_bits = 0;   // bit k: a sphere somewhere below child k
             for (int k = 0; k < nc; ++k) {
                 const float4 a = box[2 * (size_t)ch[k]], b = box[2 * (size_t)ch[k] + 1];
                 if (a.w < __builtin_inff()) {
                     rcode[k] = f16_bits_down(a.w);
                     spheres = true;
+                    sphere_bits |= 1u << k;
                 }
                 cmn[k][0] = a.x; cmn[k][1] = a.y; cmn[k][2] = a.z;
                 cmx[k][0] = b.x; cmx[k][1] = b.y; cmx[k][2] = b.z;
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, uint32_t level, const
             }
             BvhNode nd;
             nd.a = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]),
-                              eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (spheres ? 0x80000000u : 0u));
+                              eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t)nc << 24) | (sphere_bits << 27) | (spheres ? 0x80000000u : 0u));
             nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
             nd.c = make_uint4(qhi[1], qhi[2], (uint32_t)ref[0], (uint32_t)ref[1]);
             nd.d = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], rcode[0] | (rcode[1] << 16), rcode[2] | (rcode[3] << 16));
@@ -935,11 +943,13 @@ int rtx_bvh_build(rtx_context* ctx) {
         // Morton keys: enough bits per axis to separate ~n cells, at most 21.
         int bits = 4;
         while (bits < 21 && (1ull << (3 * bits)) < (uint64_t)n * 4096ull) ++bits;
-        bs.key_bits = 3 * bits;
+        bs.key_bits = 3 * bits + ((s.n_spheres != 0 && s.n_tris != 0) ? 1 : 0);
         uint64_t* keys[2];
         uint32_t* vals[2];
         for (int k = 0; k < 2; ++k) { TRY(tmp.get(&keys[k], n)); TRY(tmp.get(&vals[k], n)); }
-        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, sb, bits, keys[0], vals[0]);
+        const int split_kinds = (s.n_spheres != 0 && s.n_tris != 0) ? 1 : 0;
+        const int key_bits = 3 * bits + split_kinds;
+        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, sb, bits, split_kinds, keys[0], vals[0]);
 
         const uint32_t nb = (n + kSortTile - 1) / kSortTile;
         const uint32_t m = 256u * nb;
@@ -948,7 +958,7 @@ int rtx_bvh_build(rtx_context* ctx) {
         TRY(tmp.get(&hist, m));
         TRY(tmp.get(&partial, np));
         int cur = 0;
-        for (int shift = 0; shift < 3 * bits; shift += 8) {
+        for (int shift = 0; shift < key_bits; shift += 8) {
             hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kThreads), 0, st, keys[cur], n, shift, hist, nb);
             hipLaunchKernelGGL(k_scan_partial, dim3(np), dim3(kThreads), 0, st, hist, m, partial);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kThreads), 0, st, partial, np);

@@ -26,10 +26,10 @@
 //
 // BvhNode (64 B, four quads): a 4-wide node with quantised child boxes; one traversal
 // step covers two levels of the binary tree for one 64-byte fetch.
-//   a = (bits(origin.x), bits(origin.y), bits(origin.z), ex | ey<<8 | ez<<16 | n_children<<24 | spheres<<31)
+//   a = (bits(origin.x), bits(origin.y), bits(origin.z), ex | ey<<8 | ez<<16 | n_children<<24 | child_spheres<<27 | spheres<<31)
 //       origin = lower corner of the node's box; e* = biased f32 exponent of the per-axis
 //       grid step (step = 2^(e-127)); n_children = 2..4, children are packed first;
-//       spheres = 1 when some child's subtree holds a sphere
+//       spheres = 1 when some child's subtree holds a sphere; child_spheres: bit k = child k's does
 //   b = (qlo_x[4], qlo_y[4], qlo_z[4], qhi_x[4])   one byte per child: plane = origin + q * step
 //   c = (qhi_y[4], qhi_z[4], ref[0], ref[1])
 //   d = (ref[2], ref[3], rmin[0] | rmin[1]<<16, rmin[2] | rmin[3]<<16)
@@ -190,6 +190,10 @@ struct rtx_context {
         rtx_render_stats stats{};                 // ready when !deferred
         std::vector<hipEvent_t> events;           // this slot's own events (frames in flight must not share them)
         hipEvent_t f0 = nullptr, f1 = nullptr, a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> closest_events, shadow_events;   // a frame of several levels left in flight
+        uint64_t hint_key[4] = {0, 0, 0, 0};
+        bool multi_level = false;
+        uint32_t levels = 0;
         uint64_t primary = 0;
         bool has_shadow = false;
         // arguments, to render the frame again if its queues overflowed
@@ -200,6 +204,18 @@ struct rtx_context {
         std::vector<rtx_camera> cameras;          // empty: the scene's camera
     };
     AsyncSlot async_slots[2];
+    // What the last frame of a given shape told about its ray tree: how many levels had rays, and how many each.
+    // The next frame of that shape enqueues that many levels (plus one) without asking the device in between -- one
+    // wait per frame instead of one per level -- sizes their launches from the counts, and is rendered again level by
+    // level if its ray tree turned out deeper (Ctl::spec_miss).
+    struct LevelHint {
+        uint64_t key[4];                       // (w, h) (depth, samples) (rank, world, frames) (first ray of the batch)
+        uint32_t levels_used;
+        uint32_t rays[RTX_MAX_DEPTH + 2];
+    };
+    std::vector<LevelHint> level_hints;
+    int64_t opt_level_hints = 1;
+    bool render_without_hints = false;   // the next rtx_render_impl call asks the device level by level (a frame rendered again after a miss)
     uint32_t async_head = 0, async_count = 0;     // oldest slot, frames waiting
     // Recorded launch sequences (hipGraph) of single-batch, single-level frames rendered through the async entry
     // points with kernel timing off: replaying one costs the host one call instead of about ten. Keyed by everything the launches depend on.

@@ -30,10 +30,12 @@ struct Ctl {
     uint32_t n_nodes;
     uint32_t pool_base;
     uint32_t overflow;
-    uint32_t pad0[2];
+    uint32_t spec_miss;   // levels were enqueued without asking how many the ray tree has, and it had more (see LevelHint)
+    uint32_t pad0[1];
     uint32_t pad[1];
     uint32_t unit_head[2][8][32];   // per-shard work counters (closest, shadow), one 128-byte line each
     uint32_t level_start[RTX_MAX_DEPTH + 2];
+    uint32_t level_rays[RTX_MAX_DEPTH + 2];   // rays traced at each level of the batch (level 0: its primary rays)
     unsigned long long stat[7];    // primary, shadow, reflect, refract, skipped, nodes, panic
     unsigned long long saved[7];   // snapshot at batch start, restored when a batch is re-rendered
 };
@@ -150,6 +152,9 @@ __global__ void k_batch_init(Ctl* ctl, uint32_t n, int rollback, int first, CamS
         else ctl->saved[k] = ctl->stat[k];
     }
     ctl->overflow = 0;
+    ctl->spec_miss = 0;
+    for (int k = 0; k < (int)RTX_MAX_DEPTH + 2; ++k) ctl->level_rays[k] = 0;
+    ctl->level_rays[0] = n;
     for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[0] = n;
     ctl->n_rays[1] = 0;
@@ -1135,7 +1140,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_b(DevScene s, Work wk, int 
     }
 }
 
-__global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t cap_rays) {
+// last_enqueued: no further level follows although the frame's depth would allow one (the host enqueued as many
+// levels as the previous frame used, plus one): rays left for it mean that the frame has to be rendered again.
+__global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t cap_rays, int last_enqueued) {
     ctl->stat[ST_NODES] += min(ctl->n_nodes, cap_rays);
     ctl->pool_base += min(ctl->n_nodes, cap_rays);
     ctl->level_start[level + 1] = ctl->pool_base;
@@ -1143,6 +1150,8 @@ __global__ void k_next_level(Ctl* ctl, int q_consumed, uint32_t level, uint32_t 
     for (int k = 0; k < 8; ++k) ctl->unit_head[0][k][0] = ctl->unit_head[1][k][0] = 0;
     ctl->n_rays[q_consumed] = 0;
     if (ctl->n_rays[q_consumed ^ 1] > cap_rays) ctl->n_rays[q_consumed ^ 1] = cap_rays;
+    ctl->level_rays[level + 1] = ctl->n_rays[q_consumed ^ 1];
+    if (last_enqueued && ctl->n_rays[q_consumed ^ 1] != 0) ctl->spec_miss = 1;
 }
 
 // Backward pass, one level per launch from the deepest up: a node's final colour goes into
@@ -1435,6 +1444,7 @@ uint64_t rtx_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
 }
 
 void rtx_clear_graphs(rtx_context* ctx) {
+    ctx->level_hints.clear();   // same occasions: another scene, another tree, other options
     if (ctx->graphs.empty()) {
         ++ctx->graph_epoch;
         return;
@@ -1444,6 +1454,29 @@ void rtx_clear_graphs(rtx_context* ctx) {
     ctx->graphs.clear();
     ++ctx->graph_epoch;
 }
+
+namespace {
+rtx_context::LevelHint* find_hint(rtx_context* ctx, const uint64_t key[4]) {
+    for (auto& hnt : ctx->level_hints)
+        if (std::memcmp(hnt.key, key, sizeof(hnt.key)) == 0) return &hnt;
+    return nullptr;
+}
+// After a batch that rendered completely: what its levels held.
+void note_levels(rtx_context* ctx, const uint64_t key[4], const Ctl& hc, uint32_t levels) {
+    rtx_context::LevelHint* hnt = find_hint(ctx, key);
+    if (!hnt) {
+        if (ctx->level_hints.size() >= 64) ctx->level_hints.clear();
+        ctx->level_hints.emplace_back();
+        hnt = &ctx->level_hints.back();
+        std::memcpy(hnt->key, key, sizeof(hnt->key));
+    }
+    hnt->levels_used = 0;
+    for (uint32_t l = 0; l < RTX_MAX_DEPTH + 2; ++l) {
+        hnt->rays[l] = hc.level_rays[l];
+        if (l < levels && hc.level_rays[l] > 0) hnt->levels_used = l + 1;
+    }
+}
+}  // namespace
 
 int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, uint32_t samples, uint32_t rank,
                     uint32_t world, uint8_t* d_rgb_tiles, rtx_render_stats* stats, bool direct, int async_slot,
@@ -1614,9 +1647,20 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
     uint32_t n_batches = 0;
     uint64_t cur_batch = batch;
     int rollback = 0;
+    bool no_hints = !ctx->opt_level_hints || ctx->render_without_hints;   // (the second: a frame being rendered again after a miss)
+    ctx->render_without_hints = false;
     for (uint64_t first = 0; first < rays_local;) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(cur_batch, rays_local - first);
         ++n_batches;
+        // Several levels without a word from the device in between, when the last frame of this shape left a hint.
+        const uint64_t hint_key[4] = {((uint64_t)w << 32) | h, ((uint64_t)depth << 32) | samples,
+                                      ((uint64_t)rank << 48) | ((uint64_t)world << 32) | n_frames, first};
+        const rtx_context::LevelHint* hint = (levels > 1 && !no_hints && cur_batch == batch) ? find_hint(ctx, hint_key) : nullptr;
+        const uint32_t levels_enq = hint ? std::min<uint32_t>(levels, hint->levels_used + 1) : levels;
+        auto hinted_rays = [&](uint32_t level) {   // launch sizing only: the kernels go by the device's own counts
+            const uint64_t r = (uint64_t)hint->rays[level] + hint->rays[level] / 4 + 8192;
+            return (uint32_t)std::min<uint64_t>(r, wk.cap_rays);
+        };
         hipLaunchKernelGGL(k_batch_init, dim3(1), dim3(1), 0, st, wk.ctl, n, rollback, n_batches == 1 ? 1 : 0, (CamSetup*)d_cams,
                            (cams_by_value && n_batches == 1) ? n_frames : 0u, cam_block);
         rollback = 0;
@@ -1634,7 +1678,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         // four-frame batch) the 4096 win, because workgroups that start as others end balance the load. k_shade_b, whose
         // passes are independent, keeps the 4096 (one round of resident workgroups measured 195 us against 141).
         const uint32_t shade_resident_a = (uint32_t)ctx->num_cus * ctx->shade_a_resident, shade_cap_b = 4096u;
-        for (uint32_t level = 0; level < levels; ++level) {
+        for (uint32_t level = 0; level < levels_enq; ++level) {
             const bool no_kt = !ctx->opt_kernel_timing;   // closest_ms / shadow_ms stay 0
             hipEvent_t a = no_kt ? nullptr : ev.next(), b = no_kt ? nullptr : ev.next();
             if (!no_kt && (!a || !b)) return rtx_fail(ctx, RTX_ERR_HIP, "hipEventCreate failed");
@@ -1660,9 +1704,15 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             hipLaunchKernelGGL(k_shade_b, dim3(blocks_for(n_rays, shade_cap_b) + (uo1 ? 1u : 0u)), dim3(RTX_BLOCK), 0, st, s, wk, qi ^ 1, depth - level, samples,
                                out_map, single_level ? 1 : 0, uo1);
             if (single_level) break;
-            hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays);
+            hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, wk.ctl, qi, level, wk.cap_rays,
+                               (hint && level + 1 == levels_enq && levels_enq < levels) ? 1 : 0);
             levels_done = level + 1;
-            if (level + 1 < levels) {
+            if (hint) {   // no question asked: the next level is sized from the last frame's count
+                if (level + 1 < levels_enq) {
+                    n_rays = hinted_rays(level + 1);
+                    qi ^= 1;
+                }
+            } else if (level + 1 < levels) {
                 RTX_HIP(ctx, hipMemcpyAsync(host_next, &wk.ctl->n_rays[qi ^ 1], 4, hipMemcpyDeviceToHost, st));
                 RTX_HIP(ctx, wait_stream(st));
                 const uint32_t next = *host_next;
@@ -1700,7 +1750,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             ctx->graphs.push_back(fresh);
         }
         if (last_batch) RTX_HIP(ctx, hipEventRecord(f1, st));
-        if (slot && single_level && n_batches == 1 && last_batch) {
+        if (slot && (single_level || hint) && n_batches == 1 && last_batch) {
             // Nothing in this frame needs the host: leave it in flight, rtx_render_wait collects it.
             slot->deferred = true;
             slot->f0 = f0;
@@ -1713,9 +1763,27 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                 slot->d = shadow_events[0].second;
             }
             slot->primary = primary;
+            slot->multi_level = !single_level;
+            if (slot->multi_level) {
+                slot->closest_events = closest_events;
+                slot->shadow_events = shadow_events;
+                std::memcpy(slot->hint_key, hint_key, sizeof(hint_key));
+                slot->levels = levels;
+            }
             return RTX_OK;
         }
         RTX_HIP(ctx, wait_stream(st));
+        if (host_ctl->spec_miss && !host_ctl->overflow) {
+            // The ray tree is deeper than the last frame's: the same rays again, level by level (counters rolled back).
+            no_hints = true;
+            rollback = 1;
+            --n_batches;
+            closest_events.clear();
+            shadow_events.clear();
+            ev.used = 2;   // f0 and f1 stay
+            continue;
+        }
+        if (!host_ctl->overflow && levels > 1 && cur_batch == batch) note_levels(ctx, hint_key, *host_ctl, levels);
         if (host_ctl->overflow) {
             // The ray tree of this batch outgrew the queues: render the same pixels again in
             // smaller batches (the workspace keeps its size, so relative capacity doubles).
@@ -1779,10 +1847,20 @@ int rtx_render_wait_impl(rtx_context* ctx, rtx_render_stats* stats) {
                                                                          : std::string("hipEventQuery: ") + hipGetErrorString(e));
         }
         const Ctl* hc = (const Ctl*)((char*)ctx->pinned + (size_t)(2 + idx) * 4096);
-        if (hc->overflow)   // rare: the frame's ray tree outgrew the queues; render it again the patient way
+        if (hc->overflow || hc->spec_miss) {
+            // rare: the frame's ray tree outgrew the queues, or was deeper than the hint it was enqueued with; render it
+            // again the patient way (a later frame may be in flight behind it on the same stream: that one keeps its
+            // own results, the stream is in order)
+            ctx->render_without_hints = true;
             return rtx_render_impl(ctx, slot.w, slot.h, slot.depth, slot.samples, slot.rank, slot.world, slot.out, stats, slot.direct, -1,
                                    slot.n_frames, slot.cameras.empty() ? nullptr : slot.cameras.data());
+        }
         note_hit_fraction(ctx, *hc, slot.primary);
+        if (slot.multi_level) {
+            note_levels(ctx, slot.hint_key, *hc, slot.levels);
+            if (stats) fill_stats(*hc, slot.primary, slot.f0, slot.f1, slot.closest_events, slot.shadow_events, 1, stats);
+            return RTX_OK;
+        }
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ce{{slot.a, slot.b}}, se;
         if (slot.has_shadow) se.emplace_back(slot.c, slot.d);
         if (stats) fill_stats(*hc, slot.primary, slot.f0, slot.f1, ce, se, 1, stats);

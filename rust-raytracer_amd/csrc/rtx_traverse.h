@@ -211,9 +211,12 @@ struct TravStack {
 // flagged, and the traversal widens ALL its children by
 //     e = sqrt(K) Dn  >=  sqrt(r^2 + K Dn^2) - r   for every r > 0,     Dn = distance to the node's farthest corner,
 // one square root per node step (a per-child margin from the smallest radius below each child -- still stored in the node --
-// cost a square root and a reciprocal per child, 75 instructions per step more, and bought little: the margin only tightens
-// for spheres with r^2 >~ K D^2, and for those it is small against r either way). Children without spheres are widened
-// too, which is harmless (a box may always be larger).
+// cost a square root and a reciprocal per child, and a margin masked per child by the node's child_spheres bits cost
+// twenty registers: both are paid in resident wavefronts; the per-radius margin only tightens for spheres with
+// r^2 >~ K D^2, and for those it is small against r either way). Widening a child without spheres is always allowed
+// (a box may be larger) but would cost a mesh of small triangles among small spheres dearly, so the build keeps the
+// two kinds apart: in a scene that has both, the primitive kind is the top bit of the Morton key (rtx_bvh.hip), the
+// root's subtrees hold one kind each, and below the root a flagged node has nothing but spheres under it.
 #ifndef RTX_SPHERE_K
 #define RTX_SPHERE_K 9.2387e-7f   // 15.5 * 2^-24
 #endif

@@ -287,3 +287,60 @@ def test_row_major_frame_overwrites_a_dirty_buffer(rtx, w, h):
         assert torch.equal(both[guard:guard + n], clean)
         assert bool((both[:guard] == 0xCD).all()) and bool((both[guard + 2 * n:] == 0xCD).all())
         assert not bool((both[guard + n:guard + 2 * n] == 0xCD).all())
+
+
+def test_levels_enqueued_from_the_last_frames_hint(rtx):
+    """Frames with several levels of rays (shade_intersection recursing, src/lib.rs:230-252). The first frame of a shape
+    asks the device after every level how many rays the next one has; later frames enqueue as many levels as the last
+    one used (plus one) in one go. Whatever the hint says the frame is the same: a repeated frame, a camera that sees
+    less of the glass (shallower ray tree), one that sees more again (deeper than the hint: rendered again level by
+    level), frames in flight through the async entry point, and with the option off."""
+    torch = pytest.importorskip("torch")
+    flat = rtx.parse_scene(scene_path("test05"))
+    w, h, depth = 120, 96, 10
+    cams = _cameras(rtx, flat, 2)
+    away = rtx.Camera()                                   # looks away from the scene: the ray tree has one level
+    for name in ("pos", "view_dir", "ortho_up"):
+        for a in range(3):
+            getattr(away, name)[a] = getattr(flat.camera, name)[a]
+    away.focal_dist, away.vertical_fov = flat.camera.focal_dist, flat.camera.vertical_fov
+    for a in range(3):
+        away.view_dir[a] = -flat.camera.view_dir[a]
+    seq = [cams[0], cams[0], cams[1], away, away, cams[0], cams[1], away, cams[1]]
+
+    def frames(hints, use_async):
+        out, stats = [], []
+        with rtx.Context(0) as ctx:
+            ctx.set_option("force_mode", 2)
+            ctx.set_option("level_hints", hints)
+            ctx.set_scene(flat)
+            ctx.build()
+            bufs = [torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0") for _ in range(len(seq))]
+            torch.cuda.synchronize()
+            if use_async:
+                pending = []
+                for k, c in enumerate(seq):
+                    if len(pending) == 2:
+                        stats.append(ctx.render_wait())
+                        pending.pop(0)
+                    ctx.render_frames_async(1, [c], w, h, depth, 1, 0, 1, bufs[k].data_ptr(), True)
+                    pending.append(k)
+                while pending:
+                    stats.append(ctx.render_wait())
+                    pending.pop(0)
+            else:
+                for k, c in enumerate(seq):
+                    stats.append(ctx.render_frames(1, [c], w, h, depth, 1, 0, 1, bufs[k].data_ptr(), True))
+            torch.cuda.synchronize()
+            out = [b.cpu().numpy().reshape(h, w, 3) for b in bufs]
+        return out, stats
+
+    ref, ref_st = frames(0, False)
+    assert ref_st[0].reflect_rays > 0 and ref_st[0].refract_rays > 0 and ref_st[3].reflect_rays == 0
+    assert ref[0].max() > 0 and not np.array_equal(ref[0], ref[2])
+    for hints, use_async in ((1, False), (1, True), (0, True)):
+        got, st = frames(hints, use_async)
+        for k in range(len(seq)):
+            assert np.array_equal(got[k], ref[k]), (hints, use_async, k)
+            for field in ("primary_rays", "shadow_rays", "reflect_rays", "refract_rays", "skipped_rays", "shaded_nodes"):
+                assert getattr(st[k], field) == getattr(ref_st[k], field), (hints, use_async, k, field)
