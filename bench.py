@@ -656,7 +656,7 @@ def main():
                                    "LBVH traversal, scene and BVH resident in HBM; one step = %d frames, rendered %d per set of launches; %s"
                                    % (flat.n_tris, (" + %d spheres" % flat.n_spheres) if flat.n_spheres else "", w, h, args.depth, fps, fpb,
                                       ("every frame has its own camera (frame k of a fly-around: the scene's camera turned by 0.004 k rad about "
-                                       "the vertical axis), so a batch holds %d DIFFERENT frames" % fpb) if use_path
+                                       "the vertical axis)" + ("" if fpb == 1 else ", so a batch holds %d DIFFERENT frames" % fpb)) if use_path
                                       else ("the scene's camera for every frame: a batch holds %d COPIES of one frame" % fpb)),
                        "cameras": "path: %d distinct cameras per batch" % fpb if use_path else "fixed: %d copies per batch" % fpb,
                        "batch_frames_differ": frames_differ,
