@@ -572,3 +572,44 @@ def test_hundreds_of_triangles_without_area(rtx, synth):
     hit = px >= 0
     assert hit.mean() > 0.1
     assert np.array_equal(_bits(tb)[hit], _bits(tx)[hit])
+
+
+def test_rays_in_the_rounding_shell_of_small_spheres_equal_exhaustive(rtx, synth):
+    """The reference's sphere test (sphere.rs:54-103) can report a hit for a ray that passes OUTSIDE a sphere: its f32
+    discriminant carries an error of up to 15 ulp of |d|^2 D^2 (D = origin-to-centre distance), so rays within
+    sqrt(r^2 + c u D^2) of the centre, c < 15, u = 2^-24, are candidates. For spheres much smaller than sqrt(u) D that
+    shell is many radii wide, far outside what a silhouette test relative to r probes. Rays aimed INTO that shell, at
+    c = 0.25 ... 16, from near and far, unit and non-unit directions: the tree (whose boxes are widened by exactly this
+    bound) must return what the loop over all primitives returns, spurious hits included."""
+    flat = synth.heightfield_scene(24, small_spheres=40000)      # r = 2.5e-4 .. 7.5e-4 above a small mesh
+    rng = np.random.default_rng(41)
+    n = 600000
+    sph = flat.sph_center_radius[rng.integers(0, flat.n_spheres, n)].astype(np.float64)
+    c0, r = sph[:, :3], sph[:, 3]
+    dist = 10.0 ** rng.uniform(-1.0, 1.2, n)                       # D = 0.1 .. 16
+    u_dir = rng.normal(size=(n, 3))
+    u_dir /= np.linalg.norm(u_dir, axis=1)[:, None]
+    ori = c0 + u_dir * dist[:, None]
+    to_c = -u_dir
+    perp = np.cross(to_c, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    cc = rng.choice([0.25, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0, 16.0], n)
+    p = np.sqrt(r * r + cc * 2.0 ** -24 * dist * dist) * rng.uniform(0.9, 1.0, n)      # distance of the centre from the ray
+    target = c0 + perp * p[:, None]
+    d = target - ori
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    d[::3] *= 10.0 ** rng.uniform(-2.0, 2.0, (len(d[::3]), 1))     # |d| from 0.01 to 100
+    ori32, d32 = ori.astype(np.float32), d.astype(np.float32)
+    with rtx.Context(0) as ctx:
+        ctx.set_option("verify_build", 1)
+        ctx.set_scene(flat)
+        ctx.build()
+        assert ctx.build_stats["uses_bvh"] == 1
+        pb, tb = ctx.intersect_batch(ori32, d32)
+        px, tx = ctx.intersect_batch(ori32, d32, exhaustive=True)
+    assert np.array_equal(pb, px), "%d of %d rays differ" % ((pb != px).sum(), n)
+    hit = px >= 0
+    assert np.array_equal(_bits(tb)[hit], _bits(tx)[hit])
+    # the shell is not empty: some rays hit a sphere although they pass outside it (what the margin is for)
+    is_sphere = hit & (px >= flat.n_tris)
+    assert is_sphere.sum() > 1000
