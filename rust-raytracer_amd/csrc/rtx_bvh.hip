@@ -124,7 +124,7 @@ __device__ __forceinline__ uint64_t spread21(uint64_t x) {  // bit i -> bit 3i
 // along its thin axis, which would interleave splits that separate nothing a ray cares about. The bounds are read
 // from device memory (k_bounds of the same stream), so the host does not wait for them.
 __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                                                      const SceneBounds* __restrict__ sb, int bits, int split_kinds, uint64_t* __restrict__ keys,
+                                                      const SceneBounds* __restrict__ sb, int bits, uint64_t* __restrict__ keys,
                                                       uint32_t* __restrict__ vals) {
     float cmin[3], max_ext = 0.0f;
 #pragma unroll
@@ -143,13 +143,11 @@ __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* _
         const float qx = fminf(fmaxf((cx - cmin[0]) * scale, 0.0f), qmax);
         const float qy = fminf(fmaxf((cy - cmin[1]) * scale, 0.0f), qmax);
         const float qz = fminf(fmaxf((cz - cmin[2]) * scale, 0.0f), qmax);
-        uint64_t key = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
-        // split_kinds (a scene with triangles AND spheres): spheres sort after all triangles, so that the hierarchy's top
-        // split separates the kinds and a node below it holds one kind only -- the traversal widens the children of nodes
-        // with spheres under them (rtx_traverse.h), which must not happen to the small triangles of a dense mesh.
-        // (bmin.w carries a sphere's radius and +inf for a triangle.)
-        if (split_kinds && a.w < __builtin_inff()) key |= 1ull << (3 * bits);
-        keys[id] = key;
+        // Triangles and spheres share one order and one tree. (Keeping the kinds apart -- the kind as the top bit of the
+        // key, so that no triangle sits under a node the traversal widens for spheres -- was measured on a mesh of 63 M
+        // small triangles with 1.3 M small spheres above it and lost 5-9 %: a tree of spheres alone culls worse than
+        // spheres filed among the triangles next to them, whichever subtree a ray walks first.)
+        keys[id] = (spread21((uint64_t)qx) << 2) | (spread21((uint64_t)qy) << 1) | spread21((uint64_t)qz);
         vals[id] = id;
     }
 }
@@ -943,13 +941,12 @@ int rtx_bvh_build(rtx_context* ctx) {
         // Morton keys: enough bits per axis to separate ~n cells, at most 21.
         int bits = 4;
         while (bits < 21 && (1ull << (3 * bits)) < (uint64_t)n * 4096ull) ++bits;
-        bs.key_bits = 3 * bits + ((s.n_spheres != 0 && s.n_tris != 0) ? 1 : 0);
+        bs.key_bits = 3 * bits;
         uint64_t* keys[2];
         uint32_t* vals[2];
         for (int k = 0; k < 2; ++k) { TRY(tmp.get(&keys[k], n)); TRY(tmp.get(&vals[k], n)); }
-        const int split_kinds = (s.n_spheres != 0 && s.n_tris != 0) ? 1 : 0;
-        const int key_bits = 3 * bits + split_kinds;
-        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, sb, bits, split_kinds, keys[0], vals[0]);
+        const int key_bits = 3 * bits;
+        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kThreads), 0, st, n, bmin, bmax, sb, bits, keys[0], vals[0]);
 
         const uint32_t nb = (n + kSortTile - 1) / kSortTile;
         const uint32_t m = 256u * nb;

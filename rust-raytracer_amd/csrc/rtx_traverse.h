@@ -214,9 +214,9 @@ struct TravStack {
 // cost a square root and a reciprocal per child, and a margin masked per child by the node's child_spheres bits cost
 // twenty registers: both are paid in resident wavefronts; the per-radius margin only tightens for spheres with
 // r^2 >~ K D^2, and for those it is small against r either way). Widening a child without spheres is always allowed
-// (a box may be larger) but would cost a mesh of small triangles among small spheres dearly, so the build keeps the
-// two kinds apart: in a scene that has both, the primitive kind is the top bit of the Morton key (rtx_bvh.hip), the
-// root's subtrees hold one kind each, and below the root a flagged node has nothing but spheres under it.
+// (a box may be larger): in a tree that mixes the kinds it happens to the triangles that share a node with a sphere,
+// and to the upper levels, where every node has a sphere somewhere below it; low nodes with triangles only -- most of
+// a mesh -- are not flagged and skip the arithmetic.
 #ifndef RTX_SPHERE_K
 #define RTX_SPHERE_K 9.2387e-7f   // 15.5 * 2^-24
 #endif

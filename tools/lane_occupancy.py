@@ -9,13 +9,17 @@ ap.add_argument("--grid", type=int, default=708)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--tune", type=str, default="")
+ap.add_argument("--depth", type=int, default=10)
+ap.add_argument("--spec", type=float, default=0.0)
+ap.add_argument("--small-spheres", type=int, default=0)
+ap.add_argument("--lib", type=str, default="librtx_hip_diag.so")
 args = ap.parse_args()
-os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", "librtx_hip_diag.so")
+os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", args.lib)
 import torch
 rtx = importlib.import_module("rust-raytracer_amd")
 synth = importlib.import_module("rust-raytracer_amd.synth")
 lib = ctypes.CDLL(os.environ["RTX_LIB"])
-flat = synth.heightfield_scene(args.grid)
+flat = synth.heightfield_scene(args.grid, spec=args.spec, small_spheres=args.small_spheres)
 with rtx.Context(0) as ctx:
     ctx.set_scene(flat)
     for i, v in enumerate([x for x in args.tune.split(",") if x]):
@@ -24,9 +28,9 @@ with rtx.Context(0) as ctx:
     img = torch.zeros(args.height * args.width * 3, dtype=torch.uint8, device="cuda:0")
     buf = (ctypes.c_ulonglong * 64)()
     for _ in range(3):
-        ctx.render_device(args.width, args.height, 10, 10, img.data_ptr())
+        ctx.render_device(args.width, args.height, args.depth, 10, img.data_ptr())
     lib.rtx_diag_counters(buf)
-    ctx.render_device(args.width, args.height, 10, 10, img.data_ptr())
+    ctx.render_device(args.width, args.height, args.depth, 10, img.data_ptr())
     assert lib.rtx_diag_counters(buf) == 0
     for name, off in (("closest", 0), ("any-hit", 32)):
         c = [int(buf[off + k]) for k in range(22)]
