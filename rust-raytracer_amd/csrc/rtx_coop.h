@@ -41,6 +41,10 @@ struct CoopLds {
     int pair[RTX_BLOCK];                  // per wavefront: donor lane by rank
 };
 
+#ifndef RTX_DONATE_MIN
+#define RTX_DONATE_MIN 16
+#endif
+constexpr int kDonateMin = RTX_DONATE_MIN;   // idle lanes that make a round of giving worth its cost (coop_trace, phase 2)
 constexpr unsigned long long kCoopMiss = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;   // t = +inf, no primitive
 
 // All 64 lanes of a wavefront must call this together (`active` = the lane has a ray).
@@ -171,7 +175,10 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
             if (~busy != 0 && don != 0) { RTX_DIAG_ADD(8, 1); RTX_DIAG_ADD(10, min(__popcll(~busy), __popcll(don))); }
         }
 #endif
-        if (~busy != 0 && don != 0) {   // wave-uniform
+        // A round of giving costs about twenty cross-lane moves, so it waits until a quarter of the lanes is idle (the
+        // phase starts with at least that many idle): rounds for one or two lanes that have just finished a small subtree
+        // were nine of ten iterations on a scene of 64 M small primitives (+2 % there for 16 against 1, 8 or 24; nothing elsewhere).
+        if (__popcll(~busy) >= kDonateMin && don != 0) {   // wave-uniform
             const int np = min(__popcll(~busy), __popcll(don));
             const int rd = __popcll(don & lt), ri = __popcll(~busy & lt);
             const bool giver = can_give && rd < np, taker = !has && ri < np;

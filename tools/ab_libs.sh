@@ -1,0 +1,12 @@
+# usage: ab.sh "<libs>" "<configs>"
+for c in $2; do for l in $1; do
+  if [ "$l" = base ]; then L=""; else L="--lib librtx_hip_$l.so"; fi
+  timeout -k 10 300 python bench.py --config $c --no-cpu-baseline --no-extras $L > gpurun_out/ab_c${c}_$l.json 2>/dev/null || exit 1
+done; done
+python - "$1" "$2" <<PY
+import json,sys
+for c in sys.argv[2].split():
+    for l in sys.argv[1].split():
+        d=json.loads(open("gpurun_out/ab_c%s_%s.json"%(c,l)).read().strip().splitlines()[-1])
+        print("config",c,l, round(d["value"]), "closest %.4f shadow %.4f"%(d["kernels"]["closest_ms"], d["kernels"]["shadow_ms"]))
+PY
