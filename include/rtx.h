@@ -168,8 +168,9 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
  *                   launches (default 32 = 8 units), byte 1 for shadow launches (default 10 = 2.5 units), RTX_DEFAULT_TUNE1; small
  *                   launches get fewer workgroups per CU accordingly
- *   "tune2"         most traversal workgroups per CU (default RTX_DEFAULT_TUNE2 = 6; values above the number a kernel is compiled to keep
- *                   resident -- 4 to 6, by kernel -- change nothing)
+ *   "tune2"         most traversal workgroups per CU (default RTX_DEFAULT_TUNE2 = 7; values above the number a kernel is compiled to keep
+ *                   resident -- 4 to 7, by kernel -- change nothing, and the seventh is only used by launches of about
+ *                   two million rays or more)
  *   "tune3"         primitives per leaf: fixed at 1 (any other value is RTX_ERR_INVALID_ARG)
  *   "cost_order"    1 (default) = level-0 traversal launches hand out their work units most expensive first, using the
  *                   durations recorded by the previous frame of the same size; 0 = always index order. Never changes results.
@@ -185,7 +186,7 @@ int rtx_set_option(rtx_context* ctx, const char* key, int64_t value);
  * tools that restore a default read them here. */
 #define RTX_DEFAULT_TUNE0 48
 #define RTX_DEFAULT_TUNE1 (32 + (10 << 8)) /* 8 units per closest-hit wavefront, 2.5 per shadow wavefront */
-#define RTX_DEFAULT_TUNE2 6
+#define RTX_DEFAULT_TUNE2 7
 
 /* ---- scene ---------------------------------------------------------------
  * Replaces RayTracer::set_scene (src/lib.rs:64-67): copies the flattened scene

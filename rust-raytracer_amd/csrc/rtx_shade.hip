@@ -1355,7 +1355,10 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
 // unit and caches, and the expensive-first unit order needs more than one unit per wavefront).
 uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units, int resident) {
     // `resident`: workgroups per CU the kernel is compiled for (closest_waves / shadow_waves)
-    const uint32_t max_per_cu = std::min<uint32_t>((uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8), (uint32_t)resident);
+    uint32_t max_per_cu = std::min<uint32_t>((uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8), (uint32_t)resident);
+    // A seventh workgroup per CU pays when every wavefront still gets a long run of units (a batch of frames); a launch of
+    // one 1080p frame -- eight units per wavefront at seven workgroups -- ends later with it than without.
+    if (max_per_cu > 6 && expected_items / 64.0 < 24.0 * (double)ctx->num_cus * 7.0 * (RTX_BLOCK / 64)) max_per_cu = 6;
     const double waves = expected_items / 64.0 * 4.0 / (double)std::max<uint32_t>(quarter_units, 1);
     const double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
     const uint32_t wgs_per_cu = (uint32_t)std::min<double>(std::max<double>(per_cu, 1.0), (double)max_per_cu);

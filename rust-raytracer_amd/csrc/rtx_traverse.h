@@ -36,11 +36,13 @@
 // waves, their LDS (stacks 16 KiB + shared slots 3 KiB + the copy of the tree's top levels) is sized to fit it, and
 // launches ask for no more workgroups per CU than that (more would queue behind the others and end the launch late).
 //   closest hit:           triangle-only 74 registers, with spheres 76-77 -> 6 (80 registers is the limit for six)
-//   any-hit shadow rays:   triangle-only 75-78, with spheres 76-79 -> 6
+//   any-hit shadow rays:   triangle-only without area lights 71 -> 7 (72 registers is the limit for seven; the seventh workgroup
+//                          is only used by launches long enough to feed it, see trav_blocks: +3.4 % on a launch of eight
+//                          1080p frames, -3 % on one frame's launch); with area lights 73-74, with spheres 76-79 -> 6
 //   closest-hit shadow rays (transparent materials): triangle-only 88, with spheres 95-96 -> 5
 // (tools/kernel_resources.sh prints the compiler's figures: none of them uses scratch.)
 constexpr int closest_waves(bool sph) { return 6; }
-constexpr int shadow_waves(bool any, bool area, bool sph) { return any ? 6 : 5; }
+constexpr int shadow_waves(bool any, bool area, bool sph) { return any ? ((!area && !sph) ? 7 : 6) : 5; }
 #define RTX_WAVES_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // Which kernels a scene runs on: the triangle-only ones unless it holds spheres or triangles that every ray has to test
 // (DevScene::always; rare enough to share the general kernels, compiled once more with that loop).
@@ -353,8 +355,8 @@ struct Fetched {
 // cycles each); the same fetch from LDS is four ds_read_b128 (~16 cycles) with a fraction of the latency.
 // How many: as many as the LDS left by the kernel's resident workgroups holds (160 KiB per CU; a workgroup's stacks
 // and shared slots take 19 KiB): 4 workgroups -> 320 nodes (20 KiB, levels 0-4 of a full tree), 5 -> 128, 6 -> 64
-// (levels 0-2 and most of level 3). The cache is worth 1-2 %, a resident workgroup 5-12 %.
-constexpr uint32_t top_nodes(int waves) { return waves <= 4 ? 320u : waves == 5 ? 128u : 64u; }
+// (levels 0-2 and most of level 3), 7 -> 48. The cache is worth 1-2 %, a resident workgroup 3-12 %.
+constexpr uint32_t top_nodes(int waves) { return waves <= 4 ? 320u : waves == 5 ? 128u : waves == 6 ? 64u : 48u; }
 typedef unsigned int rtx_u32x4 __attribute__((ext_vector_type(4)));
 struct TopCache {
     RTX_LDS_PTR(rtx_u32x4) base;
