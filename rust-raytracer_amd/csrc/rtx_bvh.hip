@@ -374,7 +374,44 @@ __global__ __launch_bounds__(kThreads) void k_karras(const uint64_t* __restrict_
 
 struct PadParams {
     float rel;        // boxes grow by rel * (largest |coordinate| of the box)
+    float cam[3];     // the camera the safe region is laid around (rtx_bvh_build)
 };
+
+// Extra padding for a triangle whose two edges at v0 are less than 30 degrees apart. Moeller-Trumbore's t (poly.rs:149-176)
+// is -(s.N) / (d.N) with N = e1 x e2 and s = origin - v0, and both dot products are sums of products of magnitude
+// |s| |e1| |e2| (|d| |e1| |e2|) with a result of magnitude |s| |N| (|d| |N|): their rounding errors, a few u of the large
+// magnitude each, move the reported hit along the ray by about
+//     c u dist / sin(theta0),   theta0 = angle between e1 and e2, dist = distance from the ray origin, c ~ 16,
+// -- and, for a ray that grazes the plane, out of the plane by the same amount however small the angle of incidence.
+// For ordinary triangles that is inside the standard padding (128 u of the coordinates on the box side plus 128 u of the
+// origin on the ray side). For a needle it is not: its reported t can lie in front of its own box, and once a bound on t
+// exists (another hit, the light's distance) the box is culled although the exhaustive loop (scene/mod.rs:186-199) would
+// have replaced the hit -- seen with an exact duplicate of a needle of 1.1e-3 rad, where the lower index must win the tie
+// and lost it. The ray origins a tree has to answer for lie in the safe cube (DevScene::safe_r; others take the
+// exhaustive loop), so dist <= 2.2 safe_r, and a needle's box grows by 32 u * 2.2 safe_r / sin(theta0) on every side:
+// 0.06 % of safe_r at the 1e-3 rad below which a triangle is tested by every ray anyway (DevScene::always).
+__device__ float sliver_pad(const float* __restrict__ p, const SceneBounds* __restrict__ sb, const float cam[3]) {
+    const V3 v0 = v3(p[0], p[1], p[2]);
+    const V3 e1 = v3(p[3], p[4], p[5]) - v0, e2 = v3(p[6], p[7], p[8]) - v0;
+    const V3 c = vcross(e1, e2);
+    const float cc = vdot(c, c), ll = vdot(e1, e1) * vdot(e2, e2);
+    if (!(cc < 0.25f * ll)) return 0.0f;   // sin(theta0) >= 0.5, a degenerate product, or NaN
+    const float sn = fmaxf(sqrtf(cc / ll), 5e-4f);
+    // the safe cube's half side as rtx_bvh_build computes it from the same bounds
+    float radius = 0.0f, dcam = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t lo = sb->bmin[k], hi = sb->bmax[k];
+        const float mn = __uint_as_float(lo ^ ((lo >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        const float mx = __uint_as_float(hi ^ ((hi >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        radius = fmaxf(radius, 0.5f * (mx - mn));
+        dcam = fmaxf(dcam, fabsf(cam[k] - (0.5f * mn + 0.5f * mx)));
+    }
+    if (!(radius < __builtin_inff())) radius = 0.0f;
+    if (!(dcam < __builtin_inff())) dcam = 0.0f;
+    const float safe_r = fmaxf(fmaxf(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f);
+    return (32.0f * 5.9604645e-8f * 2.2f * 1.01f) * safe_r / sn;
+}
 
 // Positive finite f32 -> f16 bits, rounded toward zero (NaN and values <= 0 give 0).
 __device__ __forceinline__ uint32_t f16_bits_down(float r) {
@@ -404,6 +441,7 @@ __device__ __forceinline__ uint32_t f16_bits_down(float r) {
 // step cost this launch a factor of five). Every box also goes to box[] with a plain store for the launches that follow.
 // *root_height receives the height of the binary tree. rtx_set_option("verify_build") recomputes every box afterwards.
 __global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, const uint32_t* __restrict__ sorted_ids,
+                                                     const SceneBounds* __restrict__ sb,
                                                      const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                                                      BuildNode* __restrict__ bn, float4* __restrict__ box, PadParams pp, int leaf_max,
                                                      uint32_t* __restrict__ root_height) {
@@ -421,12 +459,14 @@ __global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, cons
         const uint32_t id = sorted_ids[j];
         const float4 a = bmin[id], b = bmax[id];
         const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
-        const float pad = pp.rel * m + 1e-30f;
+        float pad = pp.rel * m + 1e-30f;
         const uint32_t ref = s.prim_ref[id];
         float rmin = __builtin_inff();
         if (ref >> 31) {
             rmin = fabsf(s.sph[ref & 0x7fffffffu].w);
             if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
+        } else {
+            pad += sliver_pad(s.tri_pos + (size_t)(ref & 0x7fffffffu) * 9, sb, pp.cam);
         }
         me = (int)((n - 1) + j);
         mn = make_float4(a.x - pad, a.y - pad, a.z - pad, rmin);
@@ -926,6 +966,7 @@ int rtx_bvh_build(rtx_context* ctx) {
     s.pad_rel = 1.0f / 131072.0f;   // 2^-17, about 128 ulp of the coordinate magnitude
     PadParams pp;
     pp.rel = s.pad_rel;
+    for (int k = 0; k < 3; ++k) pp.cam[k] = ctx->camera.pos[k];
 
     const int leaf_max = RTX_LEAF_MAX;   // the traversal kernels test exactly the record a leaf reference points at
     uint32_t levels4 = 0;   // height of the 4-wide tree
@@ -984,7 +1025,7 @@ int rtx_bvh_build(rtx_context* ctx) {
         TRY_HIP(hipMemsetAsync(lvl, 0, (kMaxLevels + 2) * sizeof(LevelInfo), st));
         TRY_HIP(hipMemsetAsync(root_height, 0, 4, st));
         hipLaunchKernelGGL(k_karras, dim3((n - 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, skeys, (int)n, bn);
-        hipLaunchKernelGGL(k_refit, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, bmin, bmax, bn, box, pp, leaf_max,
+        hipLaunchKernelGGL(k_refit, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, s, n, sids, sb, bmin, bmax, bn, box, pp, leaf_max,
                            root_height);
         uint32_t* mismatches = nullptr;
         if (ctx->opt_verify_build) {

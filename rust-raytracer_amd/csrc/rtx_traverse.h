@@ -24,7 +24,9 @@
 // (tools/fuzz_bvh.py counts such rays apart: a few per hundred thousand rays aimed
 // along edges and through planes on purpose, none among rays in general position).
 // Triangles without an area are the same case for EVERY ray; they are kept out of
-// the boxes' hands and tested by all rays (DevScene::always).
+// the boxes' hands and tested by all rays (DevScene::always). Needles -- edges at v0
+// between 1e-3 and 0.5 rad apart -- report a t that is off by far more than an ordinary
+// triangle's; their boxes are padded in proportion (sliver_pad, rtx_bvh.hip).
 #pragma once
 #include "rtx_internal.h"
 

@@ -24,3 +24,15 @@ def test_bvh_equals_exhaustive_on_random_scenes(family, first, count):
                         "--scenes", str(count), "--seconds", "100", "--rays", "100000"], capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "scenes with mismatches: 0" in r.stdout
+
+
+def test_tie_between_a_needle_and_its_duplicate():
+    """Seed 26634 of family 0 with the tool's default 200 000 rays: a triangle whose edges at v0 are 1.04e-3 rad apart, in an
+    axis-aligned plane, with an exact duplicate 928 indices above it. The reference's test reports its hit 4e-5 in front of
+    the plane (the error of poly.rs:149-176 grows with 1 / sin of that angle), outside a box padded for ordinary triangles:
+    with the duplicate found first the original's box was culled and the higher index won the tie (rays 28061 and 38617).
+    The build pads needles in proportion (sliver_pad, rtx_bvh.hip)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bvh.py"), "--family", "0", "--first-seed", "26634",
+                        "--scenes", "1", "--seconds", "100"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "scenes with mismatches: 0" in r.stdout

@@ -613,3 +613,58 @@ def test_rays_in_the_rounding_shell_of_small_spheres_equal_exhaustive(rtx, synth
     # the shell is not empty: some rays hit a sphere although they pass outside it (what the margin is for)
     is_sphere = hit & (px >= flat.n_tris)
     assert is_sphere.sum() > 1000
+
+
+def test_duplicated_needle_triangles_keep_the_lowest_index(rtx, synth):
+    """A triangle whose edges at v0 are a few milliradians apart reports its t with an error far above that of an ordinary
+    triangle (poly.rs:149-176: both dot products of t cancel by the sine of that angle), up to in front of a box padded for
+    ordinary rounding. With an exact duplicate of it in the scene the loop of scene/mod.rs:186-199 keeps the lower index;
+    a tree that culled the original's box against the duplicate's t would answer with the higher one. Needles of
+    1.05e-3 ... 0.5 rad, each with a copy at a higher index, among ordinary triangles; rays aimed at them, traversed one
+    ray per wavefront (all of it in the shared phase), in full wavefronts and with sharing from the first step."""
+    rng = np.random.default_rng(26634)
+    flat = synth.heightfield_scene(48)
+    k = 1500
+    v0 = rng.uniform(-1.0, 1.0, (k, 3)) * np.array([1.0, 0.2, 1.0]) + np.array([0.0, 0.45, 0.0])
+    u = rng.normal(size=(k, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    w = rng.normal(size=(k, 3)); w -= (w * u).sum(axis=1, keepdims=True) * u; w /= np.linalg.norm(w, axis=1, keepdims=True)
+    theta = 10 ** rng.uniform(np.log10(1.05e-3), np.log10(4e-3), (k, 1))      # just above the angle below which every ray tests a triangle
+    theta[::3] = 10 ** rng.uniform(np.log10(4e-3), np.log10(0.5), (len(theta[::3]), 1))
+    length = 10 ** rng.uniform(-2.0, -0.5, (k, 1))
+    e1 = u * length
+    e2 = (u * np.cos(theta) + w * np.sin(theta)) * length * rng.uniform(0.5, 1.5, (k, 1)) * rng.choice([-1.0, 1.0], (k, 1))
+    needles = np.stack([v0, v0 + e1, v0 + e2], axis=1).astype(np.float32)
+    needles[: k // 2, :, 1] = needles[: k // 2, :1, 1]                  # half of them in axis-aligned planes (boxes without thickness)
+    n0 = flat.n_tris
+    flat.tri_pos = np.concatenate([flat.tri_pos, needles, needles])      # originals at n0 .. n0+k-1, copies above
+    flat.tri_mat = np.concatenate([flat.tri_mat, np.tile(flat.tri_mat[:1], (2 * k, 1))])
+    flat.tri_flags = np.concatenate([flat.tri_flags, np.zeros((2 * k,), np.uint8)])
+    n = 400000
+    which = rng.integers(0, k, n)
+    bary = rng.dirichlet((1, 1, 1), n)
+    target = (needles[which].astype(np.float64) * bary[:, :, None]).sum(axis=1)
+    ori = (rng.uniform(-4.0, 4.0, (n, 3)) + np.array([0.0, 1.0, 0.0])).astype(np.float32)      # inside the safe cube, far from most needles
+    d = (target - ori).astype(np.float32)
+    d[::3] /= np.linalg.norm(d[::3], axis=1, keepdims=True)
+    d[1::3] *= (10 ** rng.uniform(-2, 2, (len(d[1::3]), 1))).astype(np.float32)
+    with rtx.Context(0) as ctx:
+        ctx.set_option("verify_build", 1)
+        ctx.set_scene(flat)
+        st = ctx.build()
+        assert st["uses_bvh"] == 1 and st["n_always"] < k // 2      # some needles fall under the angle once flattened or rounded
+        px, tx = ctx.intersect_batch(ori, d, exhaustive=True)
+        on_needle = (px >= n0) & (px < n0 + k)
+        assert on_needle.sum() > 2000 and not (px >= n0 + k).any()       # the loop never answers with a copy
+        for sharing in (48, 0, 64):
+            ctx.set_option("tune0", sharing)
+            pb, tb = ctx.intersect_batch(ori, d)
+            assert np.array_equal(pb, px), "sharing below %d busy lanes: %d rays differ, e.g. %s" % (
+                sharing, (pb != px).sum(), [(int(a), int(b)) for a, b in zip(px[pb != px][:4], pb[pb != px][:4])])
+            assert np.array_equal(_bits(tb)[px >= 0], _bits(tx)[px >= 0])
+        ctx.set_option("tune0", _rtx.DEFAULT_TUNE["RTX_DEFAULT_TUNE0"])
+        # one ray per call: a wavefront with one busy lane shares from its first step, in whatever order the lanes finish
+        worst = np.flatnonzero(on_needle)
+        worst = worst[np.argsort(theta[px[worst] - n0, 0])][:96]    # the sharpest needles that were hit
+        for i in worst:
+            p1, t1 = ctx.intersect_batch(ori[i:i + 1], d[i:i + 1])
+            assert int(p1[0]) == int(px[i]) and _bits(t1)[0] == _bits(tx)[i:i + 1][0], (int(i), int(px[i]), int(p1[0]))
