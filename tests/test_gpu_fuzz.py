@@ -36,3 +36,56 @@ def test_tie_between_a_needle_and_its_duplicate():
                         "--scenes", "1", "--seconds", "100"], capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "scenes with mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("family,first,count", [(0, 0, 60), (1, 0, 60)])
+def test_frames_of_random_scenes_equal_in_both_modes(family, first, count):
+    """Whole frames (tools/fuzz_render.py): the scenes of the generators above with matte, specular and transparent
+    materials, vertex materials, point, directional and area lights and a random camera, rendered with the tree and
+    with the exhaustive loop: the same bytes and the same ray counts, i.e. every closest-hit and every shadow query
+    (any-hit, or closest-hit with the recursion through transparent hits, lib.rs:105-141) of the frame answered alike."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_render.py"), "--family", str(family), "--first-seed", str(first),
+                        "--scenes", str(count), "--seconds", "60"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "scenes with differences: 0" in r.stdout
+
+
+def _frame_fuzzer():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_render", os.path.join(ROOT, "tools", "fuzz_render.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("family,first,count", [(0, 0, 40), (1, 0, 40)])
+def test_frames_of_random_scenes_equal_the_oracle(family, first, count, rtx, orc):
+    """The same dressed scenes (up to 3000 primitives, so that the oracle's exhaustive loop takes a second) against the CPU
+    restatement of the reference: primary hits bit for bit, every colour channel within 1/255 on at least 99.9 % of the
+    pixels of each frame, and the ray counts of lib.rs:105-141 and 201-255 -- random materials with vertex blending,
+    transparent hits on shadow rays, reflection and refraction to random depths, all three kinds of light."""
+    import numpy as np
+    gen = _frame_fuzzer()
+    done = 0
+    for seed in range(first, first + count):
+        f, kind, depth, samples = gen.make(seed, family)
+        if f is None or f.n_prims > 3000:
+            continue
+        w = h = 48
+        ref = orc.OracleScene.from_flat(f).render(w, h, depth, samples, threads=8)
+        with rtx.Context(0) as ctx:
+            ctx.set_option("force_mode", 2 if f.n_prims > 4 else 0)
+            ctx.set_scene(f)
+            ctx.build()
+            prim, t, _ = ctx.primary_hits(w, h)
+            rgb, st = ctx.render(w, h, depth, samples)
+        assert np.array_equal(prim, ref["prim_id"]), (seed, int((prim != ref["prim_id"]).sum()))
+        hit = prim >= 0
+        assert np.array_equal(t.view(np.uint32)[hit], ref["t"].view(np.uint32)[hit]), seed
+        diff = np.abs(rgb.astype(int) - ref["rgb"].astype(int)).max(axis=2)
+        assert (diff <= 1).mean() >= 0.999, "seed %d: max diff %d, within-1 %.4f" % (seed, diff.max(), (diff <= 1).mean())
+        rs = ref["stats"]
+        assert (st.shadow_rays, st.reflect_rays, st.refract_rays, st.skipped_rays, st.shaded_nodes) == \
+            (rs["shadow_rays"], rs["reflect_rays"], rs["refract_rays"], rs["last_level_rays"], rs["shaded_nodes"]), seed
+        done += 1
+    assert done >= count // 3

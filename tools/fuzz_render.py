@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of whole frames: the same random scene rendered with the tree and with the exhaustive loop
+(rtx_set_option "force_mode" 2 and 1) must give the same image, byte for byte, and the same ray counts -- every
+closest-hit and every shadow query of the frame answered alike (src/lib.rs:105-141, 201-255). Scenes come from the
+generators of tools/fuzz_bvh.py (soups, planes, duplicates, grids, needles, far offsets, spheres of all sizes) with
+random materials (matte, specular, transparent), point, directional and area lights, and a camera on a sphere around
+the scene.   usage: python tools/fuzz_render.py [--scenes N] [--seconds S] [--first-seed K] [--family 0|1]"""
+import argparse, importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rtx = importlib.import_module("rust-raytracer_amd")
+src = open(os.path.join(ROOT, "tools", "fuzz_bvh.py")).read()
+ns = {"np": np, "rtx": rtx}
+exec(src[src.index("def make_scene(rng):"):src.index("t_end = time.time()")], ns)      # the generators only
+
+
+def dress(rng, f, extent, offset):
+    """Materials, lights and camera for a generated scene."""
+    f.materials = f.materials[:0]
+    f.add_material((0.7, 0.6, 0.5))
+    f.add_material((0.3, 0.5, 0.7), specular=(0.5, 0.5, 0.5), shininess=float(rng.uniform(0.05, 0.9)))
+    f.add_material((0.1, 0.1, 0.1), specular=(0.3, 0.3, 0.3), shininess=0.4, transparency=float(rng.uniform(0.2, 0.9)))
+    f.add_material((0.9, 0.2, 0.2), specular=(0.2, 0.2, 0.2), shininess=0.1, transparency=float(rng.choice([0.0, 0.5])))
+    weights = rng.dirichlet((3, 1, 1, 1))
+    if f.n_tris:
+        f.tri_mat = np.zeros((f.n_tris, 3), np.uint32)
+        f.tri_mat[:, 0] = rng.choice(4, f.n_tris, p=weights)
+        f.tri_mat[:, 1] = rng.choice(4, f.n_tris)
+        f.tri_mat[:, 2] = rng.choice(4, f.n_tris)
+        f.tri_flags = np.where(rng.random(f.n_tris) < 0.15, rtx.TRI_VERTEX_MATERIAL, 0).astype(np.uint8)
+    if f.n_spheres:
+        f.sph_mat = rng.choice(4, f.n_spheres, p=weights).astype(np.uint32)
+    f.lights = f.lights[:0]
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.choice([rtx.LIGHT_POINT, rtx.LIGHT_POINT, rtx.LIGHT_DIRECTIONAL, rtx.LIGHT_AREA]))
+        col = tuple(rng.uniform(0.3, 1.0, 3))
+        if kind == rtx.LIGHT_DIRECTIONAL:
+            v = rng.normal(size=3)
+            f.add_light(kind, tuple(v / np.linalg.norm(v)), col)
+        elif kind == rtx.LIGHT_POINT:
+            f.add_light(kind, tuple(offset + rng.uniform(-2, 2, 3) * extent), col)
+        else:
+            c = offset + rng.uniform(-2, 2, 3) * extent
+            h = rng.uniform(0.0, 0.3, 3) * extent
+            f.add_light(kind, tuple(c - h), col, b=tuple(c + h))
+    v = rng.normal(size=3); v /= np.linalg.norm(v)
+    pos = offset + v * extent * rng.uniform(1.5, 4.0)
+    up = np.array([0.0, 1.0, 0.0]) if abs(v[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+    up = up - (up @ v) * v; up /= np.linalg.norm(up)
+    f.set_camera(tuple(pos), tuple(-v), tuple(up), float(rng.uniform(0.3, 1.2)))
+
+
+def make(seed, family):
+    """Scene `seed` of a generator family, dressed: (scene, generator kind, ray-tree depth, samples per area light)."""
+    rng = np.random.default_rng(seed)
+    if family == 0:
+        f, extent, kind = ns["make_scene"](rng)
+        offset = np.zeros(3)
+    else:
+        f, extent, kind, offset = ns["make_scene1"](rng)
+    if f.n_prims == 0:
+        return None, kind, 0, 0
+    dress(rng, f, extent, offset)
+    return f, kind, int(rng.integers(1, 6)), int(rng.integers(1, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=100)
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--family", type=int, default=0)
+    ap.add_argument("--size", type=int, default=64)
+    args = ap.parse_args()
+    t_end = time.time() + args.seconds
+    bad = done = 0
+    for seed in range(args.first_seed, args.first_seed + args.scenes):
+        if time.time() > t_end:
+            break
+        f, kind, depth, samples = make(seed, args.family)
+        if f is None:
+            continue
+        frames, counts = [], []
+        for mode in (1, 2):
+            with rtx.Context(0) as ctx:
+                ctx.set_option("verify_build", 1)
+                ctx.set_option("force_mode", mode)
+                ctx.set_scene(f)
+                ctx.build()
+                rgb, st = ctx.render(args.size, args.size, depth, samples)
+                frames.append(rgb)
+                counts.append((st.primary_rays, st.shadow_rays, st.reflect_rays, st.refract_rays, st.skipped_rays, st.shaded_nodes, st.panic_pixels))
+        diff = int((frames[0] != frames[1]).any(axis=2).sum())
+        done += 1
+        print("seed %d kind %d tris %d spheres %d lights %d depth %d samples %d rays %d lit pixels %d pixels that differ %d counts equal %s" % (
+            seed, kind, f.n_tris, f.n_spheres, len(f.lights), depth, samples, sum(counts[0][:4]), int((frames[0].max(axis=2) > 0).sum()), diff,
+            counts[0] == counts[1]), flush=True)
+        if diff or counts[0] != counts[1]:
+            bad += 1
+            ys, xs = np.nonzero((frames[0] != frames[1]).any(axis=2))
+            print("  exhaustive", counts[0], "tree", counts[1], "first pixels",
+                  [(int(x), int(y), frames[0][y, x].tolist(), frames[1][y, x].tolist()) for x, y in zip(xs[:4], ys[:4])], flush=True)
+    print("scenes:", done, "scenes with differences:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
