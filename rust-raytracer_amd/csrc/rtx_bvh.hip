@@ -52,6 +52,25 @@ __device__ __forceinline__ void prim_box(const DevScene& s, uint32_t id, V3& mn,
     }
 }
 
+// A primitive the tree is not asked about: a coordinate or the radius is not a number, infinite, or beyond 1e18 in
+// magnitude (squares of differences must stay finite in the boxes' arithmetic, and a scene's bounds must not be set by
+// a stray vertex). Such a primitive goes to DevScene::always -- every ray tests it, exactly as the loop of
+// scene/mod.rs:186-199 does, Hit(inf) of an infinite sphere included -- and its leaf is a point inside the scene.
+__device__ __forceinline__ bool prim_wild(const DevScene& s, uint32_t id) {
+    const uint32_t ref = s.prim_ref[id];
+    const uint32_t idx = ref & 0x7fffffffu;
+    bool tame = true;
+    if (ref >> 31) {
+        const float4 sp = s.sph[idx];
+        tame = fabsf(sp.x) <= 1e18f && fabsf(sp.y) <= 1e18f && fabsf(sp.z) <= 1e18f && fabsf(sp.w) <= 1e18f;
+    } else {
+        const float* p = s.tri_pos + (size_t)idx * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tame = tame && fabsf(p[k]) <= 1e18f;   // false for NaN
+    }
+    return !tame;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
@@ -66,6 +85,11 @@ __global__ __launch_bounds__(kThreads) void k_bounds(DevScene s, float4* __restr
     const float inf = __builtin_inff();
     V3 cmn = v3(inf, inf, inf), cmx = v3(-inf, -inf, -inf), amn = cmn, amx = cmx;
     for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < s.n_prims; id += gridDim.x * kThreads) {
+        if (prim_wild(s, id)) {   // marked in bmin.w, kept out of the scene's bounds
+            bmin[id] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            bmax[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            continue;
+        }
         V3 mn, mx;
         prim_box(s, id, mn, mx);
         bmin[id] = make_float4(mn.x, mn.y, mn.z, 0.0f);
@@ -139,6 +163,11 @@ __global__ __launch_bounds__(kThreads) void k_morton(uint32_t n, const float4* _
     const float scale = (max_ext > 0.0f) ? (float)(1u << bits) / max_ext : 0.0f;
     for (uint32_t id = blockIdx.x * kThreads + threadIdx.x; id < n; id += gridDim.x * kThreads) {
         const float4 a = bmin[id], b = bmax[id];
+        if (a.w != 0.0f) {   // a primitive kept out of the boxes (prim_wild): sorted behind all others
+            keys[id] = (1ull << (3 * bits)) - 1ull;
+            vals[id] = id;
+            continue;
+        }
         const float cx = a.x * 0.5f + b.x * 0.5f, cy = a.y * 0.5f + b.y * 0.5f, cz = a.z * 0.5f + b.z * 0.5f;
         const float qx = fminf(fmaxf((cx - cmin[0]) * scale, 0.0f), qmax);
         const float qy = fminf(fmaxf((cy - cmin[1]) * scale, 0.0f), qmax);
@@ -409,8 +438,9 @@ __device__ float sliver_pad(const float* __restrict__ p, const SceneBounds* __re
     }
     if (!(radius < __builtin_inff())) radius = 0.0f;
     if (!(dcam < __builtin_inff())) dcam = 0.0f;
-    const float safe_r = fmaxf(fmaxf(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f);
-    return (32.0f * 5.9604645e-8f * 2.2f * 1.01f) * safe_r / sn;
+    // (kept finite for scenes with coordinates near the end of the f32 range, whose safe cube has no finite side)
+    const float safe_r = fminf(fmaxf(fmaxf(4.0f * radius, 2.0f * dcam + 2.0f * radius), 1e-3f), 1e37f);
+    return fminf((32.0f * 5.9604645e-8f * 2.2f * 1.01f) * safe_r / sn, 1e36f);
 }
 
 // Positive finite f32 -> f16 bits, rounded toward zero (NaN and values <= 0 give 0).
@@ -457,12 +487,26 @@ __global__ __launch_bounds__(kThreads) void k_refit(DevScene s, uint32_t n, cons
     uint32_t h = 0;
     if (live) {
         const uint32_t id = sorted_ids[j];
-        const float4 a = bmin[id], b = bmax[id];
+        float4 a = bmin[id], b = bmax[id];
+        const bool wild = a.w != 0.0f;
+        if (wild) {   // tested by every ray (DevScene::always); its leaf is a point at the scene's lower corner
+            float c[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t lo = sb->bmin[k];
+                c[k] = __uint_as_float(lo ^ ((lo >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+                if (!(fabsf(c[k]) <= 1e18f)) c[k] = 0.0f;   // a scene of nothing but such primitives has no bounds
+            }
+            a = make_float4(c[0], c[1], c[2], 0.0f);
+            b = a;
+        }
         const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(b.x))), fmaxf(fabsf(b.y), fabsf(b.z)));
         float pad = pp.rel * m + 1e-30f;
         const uint32_t ref = s.prim_ref[id];
         float rmin = __builtin_inff();
-        if (ref >> 31) {
+        if (wild) {
+            // no margin, no flag: the leaf is never what finds this primitive
+        } else if (ref >> 31) {
             rmin = fabsf(s.sph[ref & 0x7fffffffu].w);
             if (!(rmin >= 0.0f)) rmin = 0.0f;   // NaN radius
         } else {
@@ -720,14 +764,17 @@ __global__ __launch_bounds__(kThreads) void k_emit4(int n, uint32_t level, const
 }
 
 // Traversal records, in `order` (sorted ids) or in id order when order == nullptr.
-// flat / n_flat (with a tree): positions of the records of triangles without an area to speak of (DevScene::always),
-// |e1 x e2| <= 1e-3 |e1| |e2|; the list holds at most s.n_prims entries, n_flat counts them.
+// flat / n_flat (with a tree): positions of the records that every ray tests (DevScene::always): triangles without an
+// area to speak of, |e1 x e2| <= 1e-3 |e1| |e2|, and primitives with non-finite or enormous coordinates (prim_wild);
+// the list holds at most s.n_prims entries, n_flat counts them.
 __global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32_t* __restrict__ order, PrimRec* __restrict__ recs,
                                                          uint32_t* __restrict__ flat, uint32_t* __restrict__ n_flat) {
     for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < s.n_prims; j += gridDim.x * kThreads) {
         const uint32_t id = order ? order[j] : j;
         const uint32_t ref = s.prim_ref[id];
         const uint32_t idx = ref & 0x7fffffffu;
+        const bool wild = flat && prim_wild(s, id);
+        if (wild) flat[atomicAdd(n_flat, 1u)] = j;
         PrimRec rc;
         if (ref >> 31) {
             const float4 sp = s.sph[idx];
@@ -744,7 +791,7 @@ __global__ __launch_bounds__(kThreads) void k_make_recs(DevScene s, const uint32
             rc.q2 = make_float4(e2.x, e2.y, e2.z, 0.0f);
             if (flat) {
                 const V3 c = vcross(e1, e2);
-                if (vdot(c, c) <= 1e-6f * vdot(e1, e1) * vdot(e2, e2)) flat[atomicAdd(n_flat, 1u)] = j;   // false for NaN: such a triangle is never hit
+                if (!wild && vdot(c, c) <= 1e-6f * vdot(e1, e1) * vdot(e2, e2)) flat[atomicAdd(n_flat, 1u)] = j;   // false for NaN: such a triangle is never hit
             }
         }
         recs[j] = rc;

@@ -74,12 +74,12 @@ RTX_D void coop_trace(const DevScene& s, const TopCache& tc, bool active, V3 o, 
             }
         } else {
             cur = 0;
-            // triangles whose test answers to rounding noise rather than to where the ray goes (DevScene::always): usually none
+            // primitives whose test answers to rounding noise or to overflow rather than to where the ray goes (DevScene::always): usually none
             for (uint32_t i = 0; ALWAYS && i < s.n_always; ++i) {
                 if (ANY) {
-                    if (any_record<false>(s.always, i, o, d, dist_light)) { best_id = 1; cur = kRefDone; break; }
+                    if (any_record<SPH>(s.always, i, o, d, dist_light)) { best_id = 1; cur = kRefDone; break; }
                 } else {
-                    test_record<false>(s.always, i, o, d, best_t, best_id);
+                    test_record<SPH>(s.always, i, o, d, best_t, best_id);
                 }
             }
         }

@@ -86,9 +86,11 @@ struct DevScene {
     // traversal-side arrays
     const PrimRec* recs;        // [n_prims]
     const BvhNode* nodes;       // [n_nodes] in level order (node 0 is the root), one slot per node
-    // Triangles without an area to speak of (two edges within 1e-3 rad of parallel, or a zero edge): the determinant of
-    // poly.rs:149-153 is rounding noise for them, so the reference's test can report a hit for a ray that passes nowhere
-    // near the triangle, which no box can promise to contain. Copies of their records: every ray tests them all.
+    // Primitives that every ray tests before it enters the tree, copies of their records. Triangles without an area to
+    // speak of (two edges within 1e-3 rad of parallel, or a zero edge): the determinant of poly.rs:149-153 is rounding noise
+    // for them, so the reference's test can report a hit for a ray that passes nowhere near the triangle, which no box can
+    // promise to contain. And primitives with a coordinate or radius that is not a number, infinite or beyond 1e18: their
+    // tests answer to overflow (an infinite sphere reports Hit(inf) for every ray), and their boxes would ruin the tree's.
     const PrimRec* always;      // [n_always]
     uint32_t n_always;
     // Rays whose origin lies outside the cube |o - safe_c|_inf <= safe_r take the

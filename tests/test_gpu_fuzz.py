@@ -89,3 +89,14 @@ def test_frames_of_random_scenes_equal_the_oracle(family, first, count, rtx, orc
             (rs["shadow_rays"], rs["reflect_rays"], rs["refract_rays"], rs["last_level_rays"], rs["shaded_nodes"]), seed
         done += 1
     assert done >= count // 3
+
+
+def test_scenes_with_non_finite_and_enormous_geometry():
+    """tools/fuzz_nonfinite.py: one percent of a scene's vertices, centres and radii replaced by NaN, +-Inf, +-1e30, 3e38,
+    denormals and signed zeros. Such primitives are tested by every ray (rtx_build_stats.n_always) and kept out of the
+    tree's boxes and of the scene's bounds, so the tree still answers like the loop of scene/mod.rs:186-199 -- Hit(inf) of
+    an infinite sphere included -- for ray batches and for frames; nothing faults, hangs or returns an error status."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_nonfinite.py"), "--scenes", "150", "--seconds", "60"],
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "with differences or errors: 0" in r.stdout
