@@ -301,7 +301,8 @@ int rtx_assemble_tiles_async(rtx_context* ctx, uint32_t width, uint32_t height, 
  *   row_major != 0 (world must be 1): d_out receives [n_frames][h][w][3];
  *   otherwise d_out receives the rank's slabs, [n_frames][rtx_tiles_per_rank()][8*8*3].
  * All frames' rays must fit one ray batch (the "batch_pixels" option, default 16 Mi rays): RTX_ERR_INVALID_ARG
- * otherwise. The _async form enqueues and returns like rtx_render_tiles_async; rtx_render_wait collects the batch
+ * otherwise. A batch whose ray tree (reflective and transparent materials, deep recursion) outgrows the node pool
+ * ("pool_factor") is rendered again one frame after the other, each in as many passes as it needs: the same images, later. The _async form enqueues and returns like rtx_render_tiles_async; rtx_render_wait collects the batch
  * (ray counts are totals over its frames). */
 #define RTX_MAX_BATCH_FRAMES 64u
 int rtx_render_frames(rtx_context* ctx, uint32_t n_frames, const rtx_camera* cameras, uint32_t width, uint32_t height,

@@ -1792,8 +1792,25 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
             // smaller batches (the workspace keeps its size, so relative capacity doubles).
             if (cur_batch <= 64)
                 return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "ray queues overflow even for one tile; raise the pool_factor option");
-            if (n_frames > 1)
-                return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "the ray queues overflowed for a batch of several frames: render fewer frames per batch or raise the pool_factor option");
+            if (n_frames > 1) {
+                // A batch is one pass by construction (a ray's index is its place in the frames' slabs), so it cannot be
+                // halved; its frames can be rendered one after the other, though, each in as many passes as it needs.
+                rtx_render_stats total{};
+                const size_t frame_bytes = direct ? (size_t)w * h * 3 : (size_t)tiles_per_rank * 64 * 3;
+                for (uint32_t fr = 0; fr < n_frames; ++fr) {
+                    rtx_render_stats one{};
+                    const rtx_camera cam = cameras ? cameras[fr] : ctx->camera;
+                    const int rc = rtx_render_impl(ctx, w, h, depth, samples, rank, world, d_rgb_tiles + fr * frame_bytes, &one, direct, -1, 1, &cam);
+                    if (rc != RTX_OK) return rc;
+                    total.primary_rays += one.primary_rays; total.shadow_rays += one.shadow_rays; total.reflect_rays += one.reflect_rays;
+                    total.refract_rays += one.refract_rays; total.skipped_rays += one.skipped_rays; total.shaded_nodes += one.shaded_nodes;
+                    total.panic_pixels += one.panic_pixels; total.render_ms += one.render_ms; total.closest_ms += one.closest_ms;
+                    total.shadow_ms += one.shadow_ms; total.closest_launches += one.closest_launches; total.shadow_launches += one.shadow_launches;
+                    total.batches += one.batches;
+                }
+                if (stats) *stats = total;
+                return RTX_OK;
+            }
             cur_batch = std::max<uint64_t>(64, (cur_batch / 2 + 63) & ~63ull);
             rollback = 1;   // k_batch_init restores the ray counters of the abandoned attempt
             continue;

@@ -54,3 +54,37 @@ def gpu_ctx_factory(rtx):
     yield make
     for c in made:
         c.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _device_buffers_are_ready_before_the_library_sees_them():
+    """The library renders on a non-blocking stream of its own, which waits for no other stream: a buffer a test has just
+    filled with torch (on torch's stream) could still be receiving that fill while the library writes it. Every entry
+    point of the binding that takes a device pointer therefore first waits for torch's current stream -- what a caller
+    has to do by contract; the library's own asynchrony is not touched by it."""
+    try:
+        import torch
+        import rtx_amd
+    except Exception:
+        yield
+        return
+    if not torch.cuda.is_available():
+        yield
+        return
+    names = ["render_device", "render_device_async", "render_tiles", "render_tiles_async", "assemble_tiles", "assemble_tiles_async",
+             "render_frames", "render_frames_async", "assemble_frames_async", "intersect_batch_device", "intersect_batch_device_noalloc",
+             "gather_frame", "gather_frames"]
+    saved = {}
+    for n in names:
+        f = getattr(rtx_amd.Context, n, None)
+        if f is None:
+            continue
+        saved[n] = f
+
+        def wrapped(self, *a, _f=f, **k):
+            torch.cuda.current_stream().synchronize()
+            return _f(self, *a, **k)
+        setattr(rtx_amd.Context, n, wrapped)
+    yield
+    for n, f in saved.items():
+        setattr(rtx_amd.Context, n, f)
