@@ -396,7 +396,7 @@ Vec3 surface_normal(Ctx& cx, const Prim& q, Vec3 direction, Vec3 point) {
 }
 const Material& mat_at(Ctx& cx, const Prim& q, int k) {
     static const Material black{};
-    if (k >= q.nmat || q.mat[k] == RTX_MATERIAL_NONE) {  // reference: index out of bounds panic (poly.rs:93)
+    if (k >= q.nmat || q.mat[k] >= cx.sc->materials.size()) {  // reference: index out of bounds panic (poly.rs:93); RTX_MATERIAL_NONE is past any list
         cx.panic = true;
         return black;
     }

@@ -259,7 +259,17 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
     if (!d->tri_flags) RTX_HIP(ctx, hipMemsetAsync(d_flags, 0, std::max<size_t>(d->n_tris, 1), ctx->stream));
     S_TRY(upload(ctx, *store, (const float4*)d->sph_center_radius, (size_t)d->n_spheres, &d_sph, kind));
     S_TRY(upload(ctx, *store, d->sph_mat, (size_t)d->n_spheres, &d_smat, kind));
-    S_TRY(upload(ctx, *store, d->materials, (size_t)d->n_materials, &d_mats));
+    // Colours are clamped to [0, 1] on the way in, as every Color the reference builds is (Color::init, material.rs:17-27;
+    // parser/mod.rs:111-114): the kernels then use them as stored.
+    std::vector<rtx_material> mats(d->materials, d->materials + d->n_materials);
+    for (rtx_material& m : mats)
+        for (int k = 0; k < 3; ++k) {
+            m.diffuse[k] = clamp01(m.diffuse[k]);
+            m.ambient[k] = clamp01(m.ambient[k]);
+            m.specular[k] = clamp01(m.specular[k]);
+            m.emissive[k] = clamp01(m.emissive[k]);
+        }
+    S_TRY(upload(ctx, *store, mats.data(), mats.size(), &d_mats));
     if (device_arrays) {
         uint32_t *d_ti = nullptr, *d_si = nullptr, *d_status = nullptr;
         auto scratch_store = std::make_shared<DevStore>();   // index arrays are only needed to build prim_ref
@@ -275,6 +285,7 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
         if (need_normals && !d->tri_normals) return rtx_fail(ctx, RTX_ERR_INVALID_ARG, "a triangle has RTX_TRI_VERTEX_NORMAL but tri_normals is NULL");
     }
     if (need_normals) S_TRY(upload(ctx, *store, d->tri_normals, (size_t)d->n_tris * 9, &d_nrm, kind));
+    s.unit_light_dirs = 1;
     std::vector<DevLight> lights(d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         DevLight l{};
@@ -284,6 +295,7 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
             l.b[k] = d->lights[i].b[k];
             l.color[k] = clamp01(d->lights[i].color[k]);   // Color::init clamps (parser/mod.rs:111-114)
         }
+        if (l.type == RTX_LIGHT_DIRECTIONAL && !(l.a[0] * l.a[0] + l.a[1] * l.a[1] + l.a[2] * l.a[2] <= 1.00001f)) s.unit_light_dirs = 0;   // also a NaN
         l.area_before = s.n_area_lights;   // counts the area lights seen so far
         if (l.type == RTX_LIGHT_AREA) ++s.n_area_lights;
         lights[i] = l;
@@ -318,7 +330,7 @@ static int scene_set_impl(rtx_context* ctx, const rtx_scene_desc* d, bool device
     ctx->lights.assign(d->lights, d->lights + d->n_lights);
     ctx->has_secondary = false;
     for (uint32_t i = 0; i < d->n_materials; ++i) {
-        const rtx_material& m = d->materials[i];
+        const rtx_material& m = mats[i];
         if (m.transparency != 0.0f) s.has_transparent = 1;
         const float sc = std::sqrt(m.specular[0] * m.specular[0] + m.specular[1] * m.specular[1] + m.specular[2] * m.specular[2]);
         if (sc > 0.0f || m.transparency > 0.0f || sc != sc || m.transparency != m.transparency) ctx->has_secondary = true;

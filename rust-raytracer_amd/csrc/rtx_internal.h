@@ -68,6 +68,7 @@ struct DevScene {
     uint32_t n_nodes;           // traversal nodes (0 without a tree)
     uint32_t has_transparent;   // some material has transparency != 0
     uint32_t n_area_lights;     // lights of type RTX_LIGHT_AREA (each takes num_samples shadow rays per hit)
+    uint32_t unit_light_dirs;   // every light direction the shading sees has length <= 1: point and area lights always (get_dir normalises, scene/mod.rs:35-59), a directional light when its `dir` is no longer than that (rtx_scene_set)
     // shading-side arrays, indexed through prim_ref by reference primitive id
     const uint32_t* prim_ref;   // [n_prims] bit 31 set = sphere; low 31 bits = index into its type's arrays
     const float* tri_pos;       // [n_tris][9]

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
         }
         __syncthreads();
         uint32_t run = chunk_first;
-        bool panic = false;
+        uint32_t panic = 0;   // nodes of this thread where the reference would have panicked
 #pragma unroll
         for (int k = 0; k < kShadeItems; ++k) {
             uint32_t before = 0, row = 0;
@@ -765,15 +765,17 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
             }
             const V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
             const HitGeom g = hit_geometry(s, (int)hit[k].x, o, d, u2f(hit[k].y), true);
-            panic |= g.panic;
+            panic += g.panic ? 1u : 0u;
             const uint32_t slot = pool_base + node;
             // The ray's direction enters the node's colour through the specular term and the children only. A material
             // with ks = 0, kt = 0 and a moderate exponent has neither (rj . v <= 1 + a few ulp, so powf stays finite and
-            // ks * powf is exactly zero, see direct_lightning): such a node does without the direction.
+            // ks * powf is exactly zero, see direct_lightning): such a node does without the direction. (|rj| is the length
+            // of the light's direction: a directional light whose `dir` is longer than 1 -- the reference uses it as
+            // given, scene/mod.rs:52-55 -- can drive powf to infinity, and 0 * inf is a NaN the reference's pixel shows.)
             const rtx_material* gm = material_or_null(s, g.mat0);
             const float gq = (gm ? gm->shininess : 0.0f) * 128.0f;
             const bool plain = (!gm || (gm->specular[0] == 0.0f && gm->specular[1] == 0.0f && gm->specular[2] == 0.0f && gm->transparency == 0.0f)) &&
-                               gq >= 0.0f && gq <= 65536.0f;
+                               gq >= 0.0f && gq <= 65536.0f && s.unit_light_dirs != 0u;
             const uint32_t nflags = (f2u(d4.w) & RTX_RAY_VACUUM) | (g.panic ? 4u : 0u) | (g.blended ? 8u : 0u) | (plain ? 0u : 16u);
             wk.nP[node] = make_float4(g.p.x, g.p.y, g.p.z, u2f(g.mat0));
             wk.nN[node] = make_float4(g.n.x, g.n.y, g.n.z, u2f(nflags));
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_a(DevScene s, Work wk, int 
                 wk.pKey[slot] = key;
             }
         }
-        if (panic) atomicAdd(&ctl->stat[ST_PANIC], 1ull);   // rare
+        if (panic) atomicAdd(&ctl->stat[ST_PANIC], (unsigned long long)panic);   // rare
         __syncthreads();
     }
 }

@@ -51,9 +51,48 @@ def dress(rng, f, extent, offset):
     f.set_camera(tuple(pos), tuple(-v), tuple(up), float(rng.uniform(0.3, 1.2)))
 
 
+def dress_oddly(rng, f, extent, offset):
+    """On top of dress(): what a careless exporter produces. Material indices past the list (the reference panics there,
+    poly.rs:84-86 and the material list's bounds check: counted as panic pixels), exponents that are negative or beyond
+    65536, transparency above 1, a light on a vertex, no light at all, a camera with a tiny or huge field of view,
+    an up vector along the view direction or a view direction of length zero."""
+    if f.n_tris and rng.random() < 0.5:
+        k = max(1, f.n_tris // 20)
+        for i, c, v in zip(rng.integers(0, f.n_tris, k), rng.integers(0, 3, k), rng.choice([4, 5, 1000, rtx.MATERIAL_NONE], k)):
+            f.tri_mat[i, c:] = v      # a poly's material list is contiguous (poly.rs:13-16): what is missing is missing from there on
+    if f.n_spheres and rng.random() < 0.5:
+        k = max(1, f.n_spheres // 20)
+        f.sph_mat[rng.integers(0, f.n_spheres, k)] = rng.choice([4, 77, rtx.MATERIAL_NONE], k)
+    m = f.materials
+    if rng.random() < 0.5:
+        m["shininess"][1] = float(rng.choice([-0.5, 0.0, 600.0, 1e30]))
+    if rng.random() < 0.3:
+        m["transparency"][2] = float(rng.choice([1.0, 1.5, -0.25]))
+    if rng.random() < 0.3:
+        m["specular"][3] = (2.0, 0.0, 1e9)
+    r = rng.random()
+    if r < 0.15:
+        f.lights = f.lights[:0]
+    elif r < 0.35 and f.n_tris:      # a light that sits ON a vertex
+        f.lights["a"][0] = f.tri_pos[int(rng.integers(0, f.n_tris)), 0]
+    c = f.camera
+    r = rng.random()
+    if r < 0.15:
+        c.vertical_fov = float(rng.choice([1e-4, 3.0, 0.0, -0.7]))
+    elif r < 0.25:
+        for i in range(3):
+            c.ortho_up[i] = c.view_dir[i]
+    elif r < 0.3:
+        for i in range(3):
+            c.view_dir[i] = 0.0
+
+
 def make(seed, family):
-    """Scene `seed` of a generator family, dressed: (scene, generator kind, ray-tree depth, samples per area light)."""
+    """Scene `seed` of a generator family, dressed: (scene, generator kind, ray-tree depth, samples per area light).
+    Families 2 and 3 are families 0 and 1 dressed oddly."""
     rng = np.random.default_rng(seed)
+    odd = family >= 2
+    family &= 1
     if family == 0:
         f, extent, kind = ns["make_scene"](rng)
         offset = np.zeros(3)
@@ -62,6 +101,9 @@ def make(seed, family):
     if f.n_prims == 0:
         return None, kind, 0, 0
     dress(rng, f, extent, offset)
+    if odd:
+        dress_oddly(rng, f, extent, offset)
+        return f, kind, int(rng.integers(0, 6)), int(rng.integers(0, 4))
     return f, kind, int(rng.integers(1, 6)), int(rng.integers(1, 4))
 
 
