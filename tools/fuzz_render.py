@@ -49,6 +49,15 @@ def dress(rng, f, extent, offset):
     up = np.array([0.0, 1.0, 0.0]) if abs(v[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
     up = up - (up @ v) * v; up /= np.linalg.norm(up)
     f.set_camera(tuple(pos), tuple(-v), tuple(up), float(rng.uniform(0.3, 1.2)))
+    if f.n_tris and rng.random() < 0.6:      # vertex normals on some triangles (poly.rs:102-105): near the face normal, or anything at all
+        face = np.cross(f.tri_pos[:, 1] - f.tri_pos[:, 0], f.tri_pos[:, 2] - f.tri_pos[:, 0]).astype(np.float64)
+        face /= np.maximum(np.linalg.norm(face, axis=1, keepdims=True), 1e-30)
+        nrm = face[:, None, :] + rng.normal(0, 0.3, (f.n_tris, 3, 3))
+        wild = rng.random(f.n_tris) < 0.1
+        nrm[wild] = rng.normal(0, 1, (int(wild.sum()), 3, 3))
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=2, keepdims=True), 1e-30)
+        f.tri_normals = nrm.astype(np.float32)
+        f.tri_flags = (f.tri_flags | np.where(rng.random(f.n_tris) < 0.3, rtx.TRI_VERTEX_NORMAL, 0)).astype(np.uint8)
 
 
 def dress_oddly(rng, f, extent, offset):
