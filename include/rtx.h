@@ -46,10 +46,8 @@ typedef enum rtx_status {
 #define RTX_MAX_DEPTH 32u
 #define RTX_MATERIAL_NONE 0xFFFFFFFFu /* absent slot of a poly's material list */
 
-/* Material: src/scene/material.rs:86-94. 14 f32 = 56 bytes. Colours are already
- * clamped to [0,1] by the parser (parser/mod.rs:111-114 -> material.rs:17-27). */
-/* Colour components outside [0, 1] are clamped when the scene is set, as every Color the reference builds is
- * (Color::init, src/scene/material.rs:17-27). */
+/* Material: src/scene/material.rs:86-94. 14 f32 = 56 bytes. The reference's parser clamps colours to [0,1]
+ * (parser/mod.rs:111-114 -> material.rs:17-27); rtx_scene_set does the same to whatever it is given. */
 typedef struct rtx_material {
     float diffuse[3];
     float ambient[3];
