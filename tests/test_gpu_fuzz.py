@@ -106,14 +106,15 @@ def test_scenes_with_non_finite_and_enormous_geometry():
     assert "with differences or errors: 0" in r.stdout
 
 
-@pytest.mark.parametrize("family", [0, 1])
+@pytest.mark.parametrize("family", [0, 1, 3])
 def test_every_way_of_asking_for_a_frame_gives_the_same_bytes(family):
     """tools/fuzz_api.py: host-buffer call, device call (the second one on level hints), three frames in flight, tile slabs
-    of 2-5 ranks assembled on the device, batches of 2-3 frames with and without cameras of their own -- under random
+    of 2-5 ranks assembled on the device, batches of 2-3 frames with and without cameras of their own, the scene handed over
+    as device arrays, a clone -- under random
     options (ray batches of 64 rays up, node pools down to one node per pixel, hints, recorded launches, timing events, cost
     order and work sharing on and off), on random dressed scenes at random odd sizes: always the plain frame's bytes. A batch
     whose ray tree outgrows the pool is rendered frame by frame; only a pool too small for ONE tile's rays is an error."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_api.py"), "--family", str(family), "--first-seed", "0",
-                        "--scenes", "80", "--seconds", "45"], capture_output=True, text=True, timeout=100)
+                        "--scenes", "80", "--seconds", "40"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "with failures: 0" in r.stdout

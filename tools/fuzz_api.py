@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fuzzing of the entry points around one frame: the same dressed random scene (tools/fuzz_render.py) rendered
   - through the host-buffer call, the device call (twice: the second frame runs on the first one's level hints), frames in
-    flight, tile slabs of 2-5 ranks assembled on the device, and batches of frames with and without cameras of their own,
+    flight, tile slabs of 2-5 ranks assembled on the device, batches of frames with and without cameras of their own, a scene
+    handed over as device arrays and a clone of its context,
   - under random options: small ray batches (several passes per frame), a small node pool (frames rendered again in
     halves), level hints, recorded launches, kernel timing, cost order and the work-sharing threshold on and off,
 must give the bytes of the plain synchronous frame of a fresh context every time.
@@ -132,6 +133,28 @@ def main():
                     got = frames.cpu().numpy()
                     if not (np.array_equal(got[0], ref) and np.array_equal(got[1], ref_other) and np.array_equal(got[-1], ref if n_fr > 2 else ref_other)):
                         fails.append("batch with cameras")
+            # the same scene handed over as device arrays (rtx_scene_set_device), and a clone of that context
+            names = {"tri_pos": np.float32, "tri_normals": np.float32, "tri_mat": np.uint32, "tri_flags": np.uint8, "tri_prim_index": np.uint32,
+                     "sph_center_radius": np.float32, "sph_mat": np.uint32, "sph_prim_index": np.uint32}
+            tensors = {}
+            for name, dt in names.items():
+                arr = getattr(f, name)
+                tensors[name] = None if arr is None or np.asarray(arr).size == 0 else \
+                    torch.from_numpy(np.ascontiguousarray(arr, dt).reshape(-1).view(np.uint8).copy()).to(dev)
+            torch.cuda.synchronize()
+            meta = {"n_tris": f.n_tris, "n_spheres": f.n_spheres, "materials": f.materials, "lights": f.lights, "camera": f.camera}
+            with rtx.Context(0) as ctx:
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                ctx.set_scene_device(meta, tensors)
+                ctx.build()
+                a, st = ctx.render(w, h, depth, samples)
+                if not np.array_equal(a, ref) or st.reference_rays != st_ref.reference_rays:
+                    fails.append("device-resident scene")
+                with ctx.clone() as twin:
+                    b, st2 = twin.render(w, h, depth, samples)
+                    if not np.array_equal(b, ref) or st2.reference_rays != st_ref.reference_rays:
+                        fails.append("clone")
         except rtx.RtxError as e:
             # a node pool too small for the ray tree of ONE tile is the documented limit of the pool_factor option
             if not (e.status == 7 and (opts["pool_factor"] < 4 or opts["batch_pixels"] < 4096) and "even for one tile" in str(e)):
