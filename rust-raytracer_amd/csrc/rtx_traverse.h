@@ -38,15 +38,16 @@
 // waves, their LDS (stacks 16 KiB + shared slots 3 KiB + the copy of the tree's top levels) is sized to fit it, and
 // launches ask for no more workgroups per CU than that (more would queue behind the others and end the launch late).
 //   closest hit:           triangle-only 74 registers, with spheres 76-77 -> 6 (80 registers is the limit for six)
-//   any-hit shadow rays:   triangle-only without area lights 71 -> 7 (72 registers is the limit for seven; the seventh workgroup
-//                          is only used by launches long enough to feed it, see trav_blocks: +3.4 % on a launch of eight
-//                          1080p frames, -3 % on one frame's launch); with area lights 73-74, with spheres 76-79 -> 6
+//   any-hit shadow rays:   without area lights 71-72 (triangle-only / with spheres: the compiler fits the latter's 76-79 into the
+//                          72 that seven need, without scratch) -> 7; the seventh workgroup is only used by launches long
+//                          enough to feed it, see trav_blocks: +3.4 % on a launch of eight 1080p frames, +3 % on the 4 M-ray
+//                          launches of the 64 M-primitive scene, -3 % on one 1080p frame's launch; with area lights 73-79 -> 6
 //   closest-hit shadow rays (transparent materials): without area lights 86-88 registers, held to 80 with 32-40 bytes of scratch -> 6
 //                          (the exception to the rule above: -2.5 to -3 % on the launch, measured on 16 M triangles with glass spheres
 //                          and on the bench scene with four); with area lights 93-96 -> 5
 // (tools/kernel_resources.sh prints the compiler's figures: no other kernel uses scratch.)
 constexpr int closest_waves(bool sph) { return 6; }
-constexpr int shadow_waves(bool any, bool area, bool sph) { return any ? ((!area && !sph) ? 7 : 6) : (area ? 5 : 6); }
+constexpr int shadow_waves(bool any, bool area, bool sph) { return any ? (!area ? 7 : 6) : (area ? 5 : 6); }
 #define RTX_WAVES_ATTR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // Which kernels a scene runs on: the triangle-only ones unless it holds spheres or triangles that every ray has to test
 // (DevScene::always; rare enough to share the general kernels, compiled once more with that loop).
