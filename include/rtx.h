@@ -351,8 +351,12 @@ int rtx_gather_frames(rtx_context* ctx, uint32_t n_frames, uint32_t width, uint3
  * not run hold zeros. */
 uint64_t rtx_debug_stamps(rtx_context* ctx, int kind, uint64_t* out, uint64_t capacity);
 
-/* The context's HIP stream as a void* (hipStream_t), for callers that order
- * their own work (collectives, events) against the library's kernels. */
+/* Streams. Every context works on a HIP stream of its own, created non-blocking: it waits for no other
+ * stream, the null stream included. Device buffers handed to an entry point must therefore be complete
+ * when the call is made (a fill or copy the caller enqueued on another stream has to have finished, or
+ * the caller makes rtx_stream wait for it with an event), and results written by an _async call are
+ * ordered against the caller's streams with events on rtx_stream.
+ * rtx_stream: the context's stream as a void* (hipStream_t). */
 void* rtx_stream(rtx_context* ctx);
 
 #ifdef __cplusplus

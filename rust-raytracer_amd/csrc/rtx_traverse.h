@@ -23,6 +23,9 @@
 // to contain that, and the tree may return the hit the ray really has instead
 // (tools/fuzz_bvh.py counts such rays apart: a few per hundred thousand rays aimed
 // along edges and through planes on purpose, none among rays in general position).
+// What decides is the noise of the barycentric coordinates, u_f32 |s| / (|e| sin(angle at v0) cos(ray, normal)) with
+// s = origin - v0: of order one for in-plane rays at an ordinary triangle, and already for rays a milliradian off the
+// plane of a needle seen from fifty times its length away (the test then reports hits several lengths beside it).
 // Triangles without an area are the same case for EVERY ray; they are kept out of
 // the boxes' hands and tested by all rays (DevScene::always). Needles -- edges at v0
 // between 1e-3 and 0.5 rad apart -- report a t that is off by far more than an ordinary

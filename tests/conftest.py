@@ -61,7 +61,7 @@ def _device_buffers_are_ready_before_the_library_sees_them():
     """The library renders on a non-blocking stream of its own, which waits for no other stream: a buffer a test has just
     filled with torch (on torch's stream) could still be receiving that fill while the library writes it. Every entry
     point of the binding that takes a device pointer therefore first waits for torch's current stream -- what a caller
-    has to do by contract; the library's own asynchrony is not touched by it."""
+    has to do by contract (include/rtx.h: "Streams"); the library's own asynchrony is not touched by it."""
     try:
         import torch
         import rtx_amd

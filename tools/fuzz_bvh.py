@@ -206,9 +206,15 @@ for seed in range(args.first_seed, args.first_seed + args.scenes):
         p0, t0 = ctx.intersect_batch(o, d, exhaustive=True)
     same = (p0 == p1) & (t0.view(np.uint32) == t1.view(np.uint32))
     total_rays += len(p0)
-    # A ray that lies IN the plane of a triangle (direction and origin both within rounding of it, ~1e-7 relative) makes
-    # the determinant of poly.rs:149-153 rounding noise: the reference's test then reports hits at arbitrary t, which no
-    # bounding box can promise to contain. Such rays are counted apart (the documented difference), everything else fails.
+    # A ray for which the determinant of poly.rs:149-153 is rounding noise makes the reference's test report hits at
+    # arbitrary t, which no bounding box can promise to contain. The barycentric coordinates are quotients
+    # [s, d, e2] / det and [d, s, e1] / det (s = origin - v0): the numerators carry a rounding error of about
+    # u |s| |d| max(|e1|, |e2|), u = 2^-23 (and the determinant itself one of u |d| |e1| |e2|: |s| below counts as at least
+    # an edge's length), so the coordinates are uncertain by
+    #     noise = u |s| |d| max(|e1|, |e2|) / |det|  =  u |s| / (|e| sin(angle at v0) cos(angle between ray and normal)).
+    # For an ordinary triangle seen from nearby that takes a ray IN its plane (direction and origin within ~1e-6 of it);
+    # a needle (small angle at v0) or a far origin widens the set in proportion. A mismatch is counted apart -- the
+    # documented difference -- when the noise reaches 3 % of the coordinates' size; everything else fails.
     in_plane = 0
     real = []
     for i in np.flatnonzero(~same):
@@ -216,14 +222,21 @@ for seed in range(args.first_seed, args.first_seed + args.scenes):
         for pid in (int(p0[i]), int(p1[i])):
             if 0 <= pid < f.n_tris:
                 tv = f.tri_pos[pid].astype(np.float64)
-                nr = np.cross(tv[1] - tv[0], tv[2] - tv[0])
+                e1, e2 = tv[1] - tv[0], tv[2] - tv[0]
+                nr = np.cross(e1, e2)
                 ln = np.linalg.norm(nr)
                 dd = d[i].astype(np.float64)
                 sv = o[i].astype(np.float64) - tv[0]
-                cosn = abs(nr @ dd) / max(ln * np.linalg.norm(dd), 1e-300)
-                off = abs(nr @ sv) / max(ln * np.linalg.norm(sv), 1e-300)
-                has_area = ln > 1e-3 * np.linalg.norm(tv[1] - tv[0]) * np.linalg.norm(tv[2] - tv[0])   # others are tested by every ray: exact
-                if has_area and cosn < 4e-6 and off < 4e-6:
+                le1, le2 = np.linalg.norm(e1), np.linalg.norm(e2)
+                has_area = ln > 1e-3 * le1 * le2   # others are tested by every ray: exact
+                det = e1 @ np.cross(dd, e2)
+                if has_area and det != 0.0:
+                    bu = (sv @ np.cross(dd, e2)) / det
+                    bv = (dd @ np.cross(sv, e1)) / det
+                    noise = 2.0 ** -23 * max(np.linalg.norm(sv), le1, le2) * np.linalg.norm(dd) * max(le1, le2) / abs(det)
+                    if noise > 0.03 * max(1.0, abs(bu), abs(bv)):
+                        lies_in = True
+                elif has_area:
                     lies_in = True
         if lies_in:
             in_plane += 1
@@ -231,10 +244,10 @@ for seed in range(args.first_seed, args.first_seed + args.scenes):
             real.append(int(i))
     in_plane_total += in_plane
     say("seed", seed, "kind", kind, "tris", f.n_tris, "spheres", f.n_spheres, "extent %.3g" % extent, "hits", int((p0 >= 0).sum()),
-        "mismatches", len(real), "rays lying in a triangle's plane that differ", in_plane)
+        "mismatches", len(real), "rays with a determinant of rounding noise that differ", in_plane)
     if real:
         bad += 1
         for i in real[:4]:
             say("  ray", i, "o", o[i].tolist(), "d", d[i].tolist(), "exhaustive", int(p0[i]), float(t0[i]), "bvh", int(p1[i]), float(t1[i]))
-say("scenes with mismatches:", bad, "rays:", total_rays, "in-plane rays that differ:", in_plane_total)
+say("scenes with mismatches:", bad, "rays:", total_rays, "rays with a determinant of rounding noise that differ:", in_plane_total)
 sys.exit(1 if bad else 0)
