@@ -712,17 +712,33 @@ def main():
                         take(ctx.render_wait())
                     torch.cuda.synchronize()
                     return tot
+                # Twice: with the events that time the traversal launches (the library's default; where the per-kernel
+                # figures come from) and without them, as plain launches (no graph replay: with an idle host thread a
+                # replayed frame costs the GPU ~10 us more than its launches cost the host).
                 ctx.set_option("kernel_timing", 1)
                 run1(0, warm1)
                 t1 = time.perf_counter()
                 tot1 = run1(warm1, n1)
                 dt1 = time.perf_counter() - t1
-                out["value_single_frame"] = tot1["traced"] / dt1 / 1e6
-                out["single_frame"] = {"Mrays_s": tot1["traced"] / dt1 / 1e6, "ms_per_frame": dt1 / n1 * 1e3, "frames": n1,
-                                       "rays_per_frame": tot1["traced"] / n1,
+                ctx.set_option("kernel_timing", 0)
+                ctx.set_option("graphs", 0)
+                run1(0, warm1)
+                t1 = time.perf_counter()
+                totp = run1(warm1, n1)
+                dtp = time.perf_counter() - t1
+                ctx.set_option("graphs", 1)
+                ctx.set_option("kernel_timing", 1)
+                out["value_single_frame"] = totp["traced"] / dtp / 1e6
+                out["single_frame"] = {"Mrays_s": totp["traced"] / dtp / 1e6, "ms_per_frame": dtp / n1 * 1e3, "frames": n1,
+                                       "rays_per_frame": totp["traced"] / n1,
+                                       "with_kernel_timing": {"Mrays_s": tot1["traced"] / dt1 / 1e6, "ms_per_frame": dt1 / n1 * 1e3,
+                                                              "closest_ms_per_frame": tot1["closest_ms"] / n1,
+                                                              "shadow_ms_per_frame": tot1["shadow_ms"] / n1},
                                        "closest_ms_per_frame": tot1["closest_ms"] / n1, "shadow_ms_per_frame": tot1["shadow_ms"] / n1,
                                        "note": "the same camera path, one frame per set of launches on one context, two frames in flight; "
-                                               "wall clock, outside the timed region of `value`"}
+                                               "wall clock, outside the timed region of `value`; options kernel_timing 0 and graphs 0 "
+                                               "(`with_kernel_timing`: the same frames with the library's default options, which "
+                                               "put four events around the traversal launches of every frame)"}
                 # one of those frames against the batch path: frame 0 of the headline's last batch, rendered alone
                 if last_cams is not None:
                     ctx.render_frames(1, [last_cams[0]], w, h, args.depth, 10, 0, 1, bufs1[0].data_ptr(), True)
@@ -797,43 +813,46 @@ def main():
             # context, same camera path, outside the timed region; its own object, not `value`).
             try:
                 w4, h4 = 3840, 2160
-                bufs4 = [torch.zeros(h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+                bufs4 = [torch.zeros(h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(3)]
                 path4 = synth.camera_path(flat_cam, 0, 110) if use_path else None
                 torch.cuda.synchronize()
                 ctx.set_option("kernel_timing", 0)
+                ctx.set_option("graphs", 0)
 
-                def run4(k0, n):
+                def run4(k0, n):      # two frames in flight, like the 1080p figure above
                     rays = 0
                     for k in range(n):
-                        if k >= 1:
+                        if k >= 2:
                             rays += ctx.render_wait().traced_rays
                         if path4 is None:
-                            ctx.render_device_async(w4, h4, args.depth, 10, bufs4[k % 2].data_ptr())
+                            ctx.render_device_async(w4, h4, args.depth, 10, bufs4[k % 3].data_ptr())
                         else:
-                            ctx.render_frames_async(1, [path4[k0 + k]], w4, h4, args.depth, 10, 0, 1, bufs4[k % 2].data_ptr(), True)
-                    rays += ctx.render_wait().traced_rays
+                            ctx.render_frames_async(1, [path4[k0 + k]], w4, h4, args.depth, 10, 0, 1, bufs4[k % 3].data_ptr(), True)
+                    for _ in range(min(n, 2)):
+                        rays += ctx.render_wait().traced_rays
                     torch.cuda.synchronize()
                     return rays
                 run4(0, 5)
                 t4 = time.perf_counter()
                 rays4 = run4(5, 100)
                 dt4 = time.perf_counter() - t4
-                out["target_4k"] = {"workload": "the same %d-triangle scene at %dx%d, depth %d, 1 GPU, 100 frames of the same camera path, frame by frame"
+                out["target_4k"] = {"workload": "the same %d-triangle scene at %dx%d, depth %d, 1 GPU, 100 frames of the same camera path, frame by frame, two frames in flight, options kernel_timing 0 and graphs 0"
                                                 % (flat.n_tris, w4, h4, args.depth),
                                     "Mrays_s": rays4 / dt4 / 1e6, "ms_per_frame": dt4 / 100 * 1e3, "rays_per_frame": rays4 / 100}
                 del bufs4
                 try:     # two 4K frames per set of launches (as many rays as the headline's eight 1080p frames)
-                    bufs4 = [torch.zeros(2 * h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+                    bufs4 = [torch.zeros(2 * h4 * w4 * 3, dtype=torch.uint8, device=dev) for _ in range(3)]
                     torch.cuda.synchronize()
 
                     def run4b(k0, n):
                         rays = 0
                         for k in range(n):
-                            if k >= 1:
+                            if k >= 2:
                                 rays += ctx.render_wait().traced_rays
                             cams2 = [path4[(k0 + 2 * k) % 110], path4[(k0 + 2 * k + 1) % 110]] if path4 is not None else None
-                            ctx.render_frames_async(2, cams2, w4, h4, args.depth, 10, 0, 1, bufs4[k % 2].data_ptr(), True)
-                        rays += ctx.render_wait().traced_rays
+                            ctx.render_frames_async(2, cams2, w4, h4, args.depth, 10, 0, 1, bufs4[k % 3].data_ptr(), True)
+                        for _ in range(min(n, 2)):
+                            rays += ctx.render_wait().traced_rays
                         torch.cuda.synchronize()
                         return rays
                     run4b(0, 3)
@@ -846,6 +865,7 @@ def main():
                     out["target_4k"]["two_frames_per_batch"] = {"error": str(e)}
             except Exception as e:
                 out["target_4k"] = {"error": str(e)}
+            ctx.set_option("graphs", 1)
             ctx.set_option("kernel_timing", 1)
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, w, h, args.depth, 10, args.cpu_stride)
