@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Frame-by-frame rate of the bench scene (one 1080p frame per set of launches, one context, two frames in flight) with and
 without the events that time the traversal launches (the "kernel_timing" option; without them the frame is replayed as a graph).
-usage: python tools/single_frame_probe.py [--frames 300] [--modes 11,01,00]"""
+One run of each process (the third or fourth, around frame 900, whatever its mode and frame size) shows a stall of 40-130 ms
+that does not come back in twelve runs: a one-off of the runtime, not a cost of the mode it happens to fall in -- repeat modes.
+usage: python tools/single_frame_probe.py [--frames 300] [--modes 11,01,00] [--width 1920 --height 1080]"""
 import argparse, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
