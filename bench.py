@@ -25,6 +25,7 @@ already exist and WORLD_SIZE must equal N.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import glob
 import hashlib
 import importlib
@@ -490,6 +491,12 @@ def main():
         for k in range(n_batches_total):
             cams_of(k)
     reset_acc()
+    # The interpreter's cyclic collector stays out of the measurements: a full collection of a process that has imported
+    # torch takes 35-40 ms, comes once after about 70 000 container allocations (a thousand frames of this loop) and
+    # would land in the timed region of one run in a few (tools/stall_probe.py shows it). Nothing here builds cycles.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     if multi and not gloo:      # set-up, like the BVH build: every (context, slab) pair renders once plainly and is recorded once
         for _ in range(3 * ring):
             step()

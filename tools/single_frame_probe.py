@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Frame-by-frame rate of the bench scene (one 1080p frame per set of launches, one context, two frames in flight) with and
 without the events that time the traversal launches (the "kernel_timing" option; without them the frame is replayed as a graph).
-One run of each process (the third or fourth, around frame 900, whatever its mode and frame size) shows a stall of 40-130 ms
-that does not come back in twelve runs: a one-off of the runtime, not a cost of the mode it happens to fall in -- repeat modes.
+The interpreter's cyclic collector is switched off: its first full collection (35-40 ms with torch imported, after about 900
+frames' worth of allocations) otherwise lands in one of the runs, whatever its mode (tools/stall_probe.py).
 usage: python tools/single_frame_probe.py [--frames 300] [--modes 11,01,00] [--width 1920 --height 1080]"""
-import argparse, importlib, os, sys, time
+import argparse, gc, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -21,6 +21,8 @@ w, h, depth = a.width, a.height, 10
 path = synth.camera_path(flat, 0, a.frames + 12)
 bufs = [torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
 torch.cuda.synchronize()
+gc.collect()
+gc.disable()
 with rtx.Context(0) as ctx:
     ctx.set_scene(flat)
     ctx.build()
