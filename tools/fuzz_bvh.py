@@ -12,6 +12,7 @@ ap.add_argument("--scenes", type=int, default=200)
 ap.add_argument("--seconds", type=float, default=400.0)
 ap.add_argument("--first-seed", type=int, default=0)
 ap.add_argument("--rays", type=int, default=200000)
+ap.add_argument("--show-noise", action="store_true", help="list the differing rays that are counted apart")
 ap.add_argument("--family", type=int, default=0, help="0: soups, planes, duplicates, grids, spheres; 1: slivers, grazing rays, far offsets, tangent rays")
 args = ap.parse_args()
 rtx = importlib.import_module("rust-raytracer_amd")
@@ -236,6 +237,10 @@ for seed in range(args.first_seed, args.first_seed + args.scenes):
                     noise = 2.0 ** -23 * max(np.linalg.norm(sv), le1, le2) * np.linalg.norm(dd) * max(le1, le2) / abs(det)
                     if noise > 0.03 * max(1.0, abs(bu), abs(bv)):
                         lies_in = True
+                        if args.show_noise:
+                            say("  noise ray", int(i), "prim", pid, "noise %.3g" % noise, "barycentrics %.4g %.4g" % (bu, bv),
+                                "sin at v0 %.3g" % (ln / (le1 * le2)), "|s| / max|e| %.3g" % (np.linalg.norm(sv) / max(le1, le2)),
+                                "exhaustive", int(p0[i]), float(t0[i]), "bvh", int(p1[i]), float(t1[i]))
                 elif has_area:
                     lies_in = True
         if lies_in:
