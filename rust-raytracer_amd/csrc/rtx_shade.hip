@@ -1355,14 +1355,21 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
 // workgroups) and sized so that a wavefront expects `quarter_units / 4` work units: a launch with
 // few units runs faster on fewer wavefronts (every step of a ray waits less for the CU's address
 // unit and caches, and the expensive-first unit order needs more than one unit per wavefront).
-uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units, int resident) {
+uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units, int resident,
+                     bool root_rule = false) {
     // `resident`: workgroups per CU the kernel is compiled for (closest_waves / shadow_waves)
     uint32_t max_per_cu = std::min<uint32_t>((uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8), (uint32_t)resident);
     // A seventh workgroup per CU pays when every wavefront still gets a long run of units (a batch of frames); a launch of
     // one 1080p frame -- eight units per wavefront at seven workgroups -- ends later with it than without.
     if (max_per_cu > 6 && expected_items / 64.0 < 24.0 * (double)ctx->num_cus * 7.0 * (RTX_BLOCK / 64)) max_per_cu = 6;
     const double waves = expected_items / 64.0 * 4.0 / (double)std::max<uint32_t>(quarter_units, 1);
-    const double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
+    double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
+    // Shadow launches of one small frame: a unit takes longer the more wavefronts share the CU, and a launch lasts about
+    // (units per wavefront) x (time per unit), so the best number of resident workgroups grows with the square root of the
+    // work, not with the work. Measured frame by frame on the bench scene (workgroups per CU: ms per frame):
+    // 1360x768 (14 400 units): 3 0.308, 4 0.305, 6 0.326;  1920x1080 (29 000): 4 0.4395, 5 0.439, 6 0.4455;  960x540 (7 200):
+    // 2 0.2406, 3 0.2357;  larger launches are capped by what the kernel keeps resident either way.
+    if (root_rule) per_cu = std::min(per_cu, std::floor(std::sqrt(expected_items / 64.0 / ((double)ctx->num_cus * (RTX_BLOCK / 64))) + 0.5));
     const uint32_t wgs_per_cu = (uint32_t)std::min<double>(std::max<double>(per_cu, 1.0), (double)max_per_cu);
     const uint64_t cap = (uint64_t)ctx->num_cus * wgs_per_cu;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items_upper + RTX_BLOCK - 1) / RTX_BLOCK, cap));
@@ -1412,7 +1419,7 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
     const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                shadow_waves(any, area, general_kernels(s))));
+                                shadow_waves(any, area, general_kernels(s)), true));
     if (any && area) launch_shadow_kernel<true, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (any) launch_shadow_kernel<true, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (area) launch_shadow_kernel<false, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
@@ -1609,7 +1616,7 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
                                  (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
                                  ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(s))) << 32) |
                                      trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                                 shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s))),
+                                                 shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s)), true),
                                  (uint64_t)(uintptr_t)wk.ctl ^ (d_cams ? 0x9e3779b97f4a7c15ull : 0ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;

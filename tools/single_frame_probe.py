@@ -8,14 +8,18 @@ import argparse, gc, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-rtx = importlib.import_module("rust-raytracer_amd")
-synth = importlib.import_module("rust-raytracer_amd.synth")
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--modes", default="11,01,00,11,01", help="kernel_timing and graphs, two digits per run")
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--lib", default="", help="another build of the library (file name in rust-raytracer_amd/)")
+ap.add_argument("--opt", action="append", default=[], help="name=value, set before the runs (e.g. tune1=8224)")
 a = ap.parse_args()
+if a.lib:
+    os.environ["RTX_LIB"] = os.path.join(ROOT, "rust-raytracer_amd", a.lib)
+rtx = importlib.import_module("rust-raytracer_amd")
+synth = importlib.import_module("rust-raytracer_amd.synth")
 flat = synth.heightfield_scene(708)
 w, h, depth = a.width, a.height, 10
 path = synth.camera_path(flat, 0, a.frames + 12)
@@ -26,6 +30,9 @@ gc.disable()
 with rtx.Context(0) as ctx:
     ctx.set_scene(flat)
     ctx.build()
+    for kv in a.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     def run(k0, n):
         rays = 0
         for k in range(n):
