@@ -1356,7 +1356,7 @@ void fill_stats(const Ctl& hc, uint64_t primary, hipEvent_t f0, hipEvent_t f1,
 // few units runs faster on fewer wavefronts (every step of a ray waits less for the CU's address
 // unit and caches, and the expensive-first unit order needs more than one unit per wavefront).
 uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expected_items, uint32_t quarter_units, int resident,
-                     bool root_rule = false) {
+                     int root_rule = 0) {
     // `resident`: workgroups per CU the kernel is compiled for (closest_waves / shadow_waves)
     uint32_t max_per_cu = std::min<uint32_t>((uint32_t)std::min<int32_t>(std::max<int32_t>(ctx->ds.tune[2], 1), 8), (uint32_t)resident);
     // A seventh workgroup per CU pays when every wavefront still gets a long run of units (a batch of frames); a launch of
@@ -1364,12 +1364,18 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
     if (max_per_cu > 6 && expected_items / 64.0 < 24.0 * (double)ctx->num_cus * 7.0 * (RTX_BLOCK / 64)) max_per_cu = 6;
     const double waves = expected_items / 64.0 * 4.0 / (double)std::max<uint32_t>(quarter_units, 1);
     double per_cu = std::ceil(waves / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
-    // Shadow launches of one small frame: a unit takes longer the more wavefronts share the CU, and a launch lasts about
-    // (units per wavefront) x (time per unit), so the best number of resident workgroups grows with the square root of the
-    // work, not with the work. Measured frame by frame on the bench scene (workgroups per CU: ms per frame):
-    // 1360x768 (14 400 units): 3 0.308, 4 0.305, 6 0.326;  1920x1080 (29 000): 4 0.4395, 5 0.439, 6 0.4455;  960x540 (7 200):
-    // 2 0.2406, 3 0.2357;  larger launches are capped by what the kernel keeps resident either way.
-    if (root_rule) per_cu = std::min(per_cu, std::floor(std::sqrt(expected_items / 64.0 / ((double)ctx->num_cus * (RTX_BLOCK / 64))) + 0.5));
+    // Launches of one small frame: a unit takes longer the more wavefronts share the CU, and a launch lasts about (units per
+    // wavefront) x (time per unit), so the best number of resident workgroups grows with the square root of the work, not
+    // with the work. Measured frame by frame on the bench scene (workgroups per CU: ms per frame).
+    // root_rule 1, shadow launches (units of rays that will be traced): 7 200 units (960x540): 2 0.2406, 3 0.2357;
+    //   14 400 (1360x768): 3 0.308, 4 0.305, 6 0.326;  29 000 (1920x1080): 4 0.4395, 5 0.439, 6 0.4455.
+    // root_rule 2, primary rays, with the rays that will hit something as the work (sky costs next to nothing) once a frame
+    //   has told their share: 8 100 units (960x540): 1 0.236, 2 0.2295;  16 300: 2 0.306, 3 0.304, 4 0.320;  32 400 (1080p):
+    //   2 0.460, 3 0.439, 4 0.443, 6 0.467;  57 600 (1440p): 3 0.6215, 4 0.612, 5 0.612, 6 0.622;  129 600 (4K): 4 1.108, 6 1.097.
+    // Larger launches are capped by what the kernel keeps resident either way.
+    const double root = std::sqrt(expected_items / 64.0 / ((double)ctx->num_cus * (RTX_BLOCK / 64)));
+    if (root_rule == 1) per_cu = std::min(per_cu, std::floor(root + 0.5));
+    if (root_rule == 2 && ctx->hit_fraction_known) per_cu = std::ceil(root * std::sqrt((double)ctx->hit_fraction));
     const uint32_t wgs_per_cu = (uint32_t)std::min<double>(std::max<double>(per_cu, 1.0), (double)max_per_cu);
     const uint64_t cap = (uint64_t)ctx->num_cus * wgs_per_cu;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((items_upper + RTX_BLOCK - 1) / RTX_BLOCK, cap));
@@ -1379,7 +1385,8 @@ uint32_t trav_blocks(const rtx_context* ctx, uint64_t items_upper, double expect
 // launch, because events recorded between launches each cost the stream several idle microseconds.
 void launch_closest(const rtx_context* ctx, const Work& wk, int qi, uint32_t n_upper, const PrimaryGen& pg, UnitOrder* uo,
                     bool shade, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(ctx->ds)))), block(RTX_BLOCK);
+    const dim3 grid(trav_blocks(ctx, n_upper, (double)n_upper, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(ctx->ds)), pg.enabled ? 2 : 0)),
+        block(RTX_BLOCK);
     uint32_t* counts = shade ? wk.chunk_cnt : nullptr;
     unsigned long long* masks = shade ? wk.hit_mask : nullptr;
     // one binary per (spheres, always-tested triangles, camera array): see primary_ray
@@ -1419,7 +1426,7 @@ void launch_shadow(const rtx_context* ctx, const Work& wk, uint32_t depth, uint6
     const bool area = s.n_area_lights != 0;
     // the share of rays that hit something is not known before the launch: the last frame's share stands in
     const dim3 grid(trav_blocks(ctx, tasks_upper, (double)tasks_upper * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                shadow_waves(any, area, general_kernels(s)), true));
+                                shadow_waves(any, area, general_kernels(s)), 1));
     if (any && area) launch_shadow_kernel<true, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (any) launch_shadow_kernel<true, false>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
     else if (area) launch_shadow_kernel<false, true>(grid, st, t0, t1, s, wk, depth, n_slots, uo);
@@ -1614,9 +1621,9 @@ int rtx_render_impl(rtx_context* ctx, uint32_t w, uint32_t h, uint32_t depth, ui
         if (s.n_lights > 0) (void)unit_order(ctx, 1, 0, ((uint64_t)wk.cap_rays * n_slots / 64 + kGroup) / kGroup);
         const uint64_t key[8] = {((uint64_t)w << 32) | h, ((uint64_t)depth << 32) | samples, ((uint64_t)rank << 32) | world,
                                  (uint64_t)(uintptr_t)d_rgb_tiles, ((uint64_t)(direct ? 1 : 0) << 32) | (uint32_t)async_slot,
-                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(s))) << 32) |
+                                 ((uint64_t)trav_blocks(ctx, n0, (double)n0, (uint32_t)ctx->ds.tune[1] & 0xffu, closest_waves(general_kernels(s)), 2) << 32) |
                                      trav_blocks(ctx, (uint64_t)n0 * n_slots, (double)n0 * n_slots * ctx->hit_fraction, ((uint32_t)ctx->ds.tune[1] >> 8) & 0xffu,
-                                                 shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s)), true),
+                                                 shadow_waves(any_shadow, s.n_area_lights != 0, general_kernels(s)), 1),
                                  (uint64_t)(uintptr_t)wk.ctl ^ (d_cams ? 0x9e3779b97f4a7c15ull : 0ull), (uint64_t)ctx->graph_epoch ^ ((uint64_t)n_frames << 56)};
         for (auto& g : ctx->graphs)
             if (std::memcmp(g.key, key, sizeof(key)) == 0) fg = &g;
