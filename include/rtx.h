@@ -167,7 +167,10 @@ const char* rtx_last_error(const rtx_context* ctx);
  *   "tune0"         lanes still busy below which a wavefront's idle lanes start taking subtrees from busy ones (default RTX_DEFAULT_TUNE0 = 48; 0 = never)
  *   "tune1"         work units (64 rays) a traversal wavefront should expect, in quarters: byte 0 for closest-hit
  *                   launches (default 32 = 8 units), byte 1 for shadow launches (default 10 = 2.5 units), RTX_DEFAULT_TUNE1; small
- *                   launches get fewer workgroups per CU accordingly
+ *                   launches get fewer workgroups per CU accordingly. Two launches do not grow with their work but with its
+ *                   square root: a shadow launch gets at most round(sqrt(units / (4 * CUs))) workgroups per CU, and the
+ *                   primary-ray launch of a frame ceil(sqrt(units * share / (4 * CUs))), share = the part of the previous
+ *                   frame's primary rays that hit something (byte 0 then only sizes the launches of deeper levels)
  *   "tune2"         most traversal workgroups per CU (default RTX_DEFAULT_TUNE2 = 7; values above the number a kernel is compiled to keep
  *                   resident -- 4 to 7, by kernel -- change nothing, and the seventh is only used by launches of about
  *                   two million rays or more)
