@@ -384,8 +384,23 @@ RTX_D void order_units(UnitOrder* uo) {
     constexpr uint32_t kHeld = 16;   // registers: 4 codes each
     uint32_t held[kHeld];
     const bool fits = per <= 4 * kHeld;
+    // Up to 32768 groups (eight 1080p frames) they are read twice, again four per load and all loads independent -- once for
+    // the largest cost, once more (from the L2) for the classes, which are four bits and go eight to a word that is parked in
+    // the place of the first of its eight costs (registers for them would be the shading blocks' registers too, LDS their
+    // LDS: both cost the launch a resident workgroup). Beyond
+    // that a thread walks its groups one load at a time: three dependent passes, 165 us for 32 400 groups when this path
+    // still served the eight-frame batch -- longer than the shading it runs beside, so the launch waited for its sort.
+    const bool fits2 = !fits && per <= 8 * kHeld;
     uint32_t mx = 0;
-    if (fits) {
+    if (fits2) {
+#pragma unroll 4
+        for (uint32_t k = 0; k < 2 * kHeld; ++k) {
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            if (lo + 4 * k < hi) c = *reinterpret_cast<const uint4*>(cost + lo + 4 * k);
+            // entries past hi inside the last word: cost[] is padded with zeros, whose code is 0
+            mx = max(max(mx, cost_code(c.x)), max(cost_code(c.y), max(cost_code(c.z), cost_code(c.w))));
+        }
+    } else if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
             uint4 c = make_uint4(0u, 0u, 0u, 0u);
@@ -404,7 +419,21 @@ RTX_D void order_units(UnitOrder* uo) {
     __syncthreads();
     const int top = (int)(s_max | 1u);   // class 0 = the upper half of the largest cost's octave
     auto cls = [top](uint32_t code) { return min(kOrderClasses - 1, top - (int)code); };
-    if (fits) {
+    if (fits2) {
+#pragma unroll 2
+        for (uint32_t r = 0; r < kHeld; ++r) {
+            uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
+            if (lo + 8 * r < hi) c0 = *reinterpret_cast<const uint4*>(cost + lo + 8 * r);
+            if (lo + 8 * r + 4 < hi) c1 = *reinterpret_cast<const uint4*>(cost + lo + 8 * r + 4);
+            const uint32_t word = (uint32_t)cls(cost_code(c0.x)) | ((uint32_t)cls(cost_code(c0.y)) << 4) | ((uint32_t)cls(cost_code(c0.z)) << 8) |
+                                  ((uint32_t)cls(cost_code(c0.w)) << 12) | ((uint32_t)cls(cost_code(c1.x)) << 16) | ((uint32_t)cls(cost_code(c1.y)) << 20) |
+                                  ((uint32_t)cls(cost_code(c1.z)) << 24) | ((uint32_t)cls(cost_code(c1.w)) << 28);
+            if (lo + 8 * r < hi) cost[lo + 8 * r] = word;   // parked where its first cost was: the costs are spent, and cleared below
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b)
+                if (lo + 8 * r + b < hi) ++offs[((word >> (4 * b)) & 0xfu) * kOrderThreads + t];
+        }
+    } else if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k)
 #pragma unroll
@@ -436,7 +465,16 @@ RTX_D void order_units(UnitOrder* uo) {
     // groups in the eight dearest half-octave classes (cost >= 1/16 of the dearest): where class 8 starts in `order`
     static_assert(kOrderClasses == 16, "class 8 is four octaves below the dearest group");
     const uint32_t dear_groups = (t == 0) ? offs[8 * kOrderThreads] : 0u;
-    if (fits) {
+    if (fits2) {
+        for (uint32_t r = 0; r < kHeld; ++r) {
+            const uint32_t word = (lo + 8 * r < hi) ? cost[lo + 8 * r] : 0u;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b)
+                if (lo + 8 * r + b < hi) order[offs[((word >> (4 * b)) & 0xfu) * kOrderThreads + t]++] = lo + 8 * r + b;
+            if (lo + 8 * r < hi) *reinterpret_cast<uint4*>(cost + lo + 8 * r) = make_uint4(0u, 0u, 0u, 0u);
+            if (lo + 8 * r + 4 < hi) *reinterpret_cast<uint4*>(cost + lo + 8 * r + 4) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else if (fits) {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
 #pragma unroll
