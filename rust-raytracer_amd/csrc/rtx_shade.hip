@@ -384,23 +384,22 @@ RTX_D void order_units(UnitOrder* uo) {
     constexpr uint32_t kHeld = 16;   // registers: 4 codes each
     uint32_t held[kHeld];
     const bool fits = per <= 4 * kHeld;
-    // Up to 32768 groups (eight 1080p frames) they are read twice, again four per load and all loads independent -- once for
-    // the largest cost, once more (from the L2) for the classes, which are four bits and go eight to a word that is parked in
-    // the place of the first of its eight costs (registers for them would be the shading blocks' registers too, LDS their
-    // LDS: both cost the launch a resident workgroup). Beyond
-    // that a thread walks its groups one load at a time: three dependent passes, 165 us for 32 400 groups when this path
-    // still served the eight-frame batch -- longer than the shading it runs beside, so the launch waited for its sort.
-    const bool fits2 = !fits && per <= 8 * kHeld;
+    // More groups than that (eight 1080p frames have 32 400) are read twice, again four per load with independent loads --
+    // once for the largest cost, once more (from the L2) for the classes, which are four bits and go eight to a word that is
+    // parked in the place of the first of its eight costs (registers for them would be the shading blocks' registers too,
+    // LDS their LDS: both cost the launch a resident workgroup). A walk of one dependent 4-byte load per group, thread and
+    // pass -- what this path replaces -- took 165 us for the eight-frame batch: longer than the shading beside it.
+    const uint32_t words4 = per / 4u, words8 = (per + 7u) / 8u;
     uint32_t mx = 0;
-    if (fits2) {
+    if (!fits) {
 #pragma unroll 4
-        for (uint32_t k = 0; k < 2 * kHeld; ++k) {
+        for (uint32_t k = 0; k < words4; ++k) {
             uint4 c = make_uint4(0u, 0u, 0u, 0u);
             if (lo + 4 * k < hi) c = *reinterpret_cast<const uint4*>(cost + lo + 4 * k);
             // entries past hi inside the last word: cost[] is padded with zeros, whose code is 0
             mx = max(max(mx, cost_code(c.x)), max(cost_code(c.y), max(cost_code(c.z), cost_code(c.w))));
         }
-    } else if (fits) {
+    } else {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
             uint4 c = make_uint4(0u, 0u, 0u, 0u);
@@ -412,16 +411,14 @@ RTX_D void order_units(UnitOrder* uo) {
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b)
                 if (lo + 4 * k + b < hi) mx = max(mx, (held[k] >> (8 * b)) & 0xffu);
-    } else {
-        for (uint32_t u = lo; u < hi; ++u) mx = max(mx, cost_code(cost[u]));
     }
     atomicMax(&s_max, mx);
     __syncthreads();
     const int top = (int)(s_max | 1u);   // class 0 = the upper half of the largest cost's octave
     auto cls = [top](uint32_t code) { return min(kOrderClasses - 1, top - (int)code); };
-    if (fits2) {
+    if (!fits) {
 #pragma unroll 2
-        for (uint32_t r = 0; r < kHeld; ++r) {
+        for (uint32_t r = 0; r < words8; ++r) {
             uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
             if (lo + 8 * r < hi) c0 = *reinterpret_cast<const uint4*>(cost + lo + 8 * r);
             if (lo + 8 * r + 4 < hi) c1 = *reinterpret_cast<const uint4*>(cost + lo + 8 * r + 4);
@@ -433,14 +430,12 @@ RTX_D void order_units(UnitOrder* uo) {
             for (uint32_t b = 0; b < 8; ++b)
                 if (lo + 8 * r + b < hi) ++offs[((word >> (4 * b)) & 0xfu) * kOrderThreads + t];
         }
-    } else if (fits) {
+    } else {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k)
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b)
                 if (lo + 4 * k + b < hi) ++offs[cls((held[k] >> (8 * b)) & 0xffu) * kOrderThreads + t];
-    } else {
-        for (uint32_t u = lo; u < hi; ++u) ++offs[cls(cost_code(cost[u])) * kOrderThreads + t];
     }
     __syncthreads();
     // Exclusive scan of the class-major, thread-minor sequence in place; thread t scans the
@@ -465,8 +460,8 @@ RTX_D void order_units(UnitOrder* uo) {
     // groups in the eight dearest half-octave classes (cost >= 1/16 of the dearest): where class 8 starts in `order`
     static_assert(kOrderClasses == 16, "class 8 is four octaves below the dearest group");
     const uint32_t dear_groups = (t == 0) ? offs[8 * kOrderThreads] : 0u;
-    if (fits2) {
-        for (uint32_t r = 0; r < kHeld; ++r) {
+    if (!fits) {
+        for (uint32_t r = 0; r < words8; ++r) {
             const uint32_t word = (lo + 8 * r < hi) ? cost[lo + 8 * r] : 0u;
 #pragma unroll
             for (uint32_t b = 0; b < 8; ++b)
@@ -474,18 +469,13 @@ RTX_D void order_units(UnitOrder* uo) {
             if (lo + 8 * r < hi) *reinterpret_cast<uint4*>(cost + lo + 8 * r) = make_uint4(0u, 0u, 0u, 0u);
             if (lo + 8 * r + 4 < hi) *reinterpret_cast<uint4*>(cost + lo + 8 * r + 4) = make_uint4(0u, 0u, 0u, 0u);
         }
-    } else if (fits) {
+    } else {
 #pragma unroll
         for (uint32_t k = 0; k < kHeld; ++k) {
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b)
                 if (lo + 4 * k + b < hi) order[offs[cls((held[k] >> (8 * b)) & 0xffu) * kOrderThreads + t]++] = lo + 4 * k + b;
             if (lo + 4 * k < hi) *reinterpret_cast<uint4*>(cost + lo + 4 * k) = make_uint4(0u, 0u, 0u, 0u);
-        }
-    } else {
-        for (uint32_t u = lo; u < hi; ++u) {
-            order[offs[cls(cost_code(cost[u])) * kOrderThreads + t]++] = u;
-            cost[u] = 0;
         }
     }
     __syncthreads();

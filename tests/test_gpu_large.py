@@ -165,16 +165,19 @@ def test_cost_ordered_units_do_not_change_the_frame(rtx, synth):
         assert np.array_equal(other, other_ref)
 
 
-@pytest.mark.parametrize("n_frames,w,h", [(8, 1920, 1080), (5, 1920, 1080), (3, 1280, 720)])
+@pytest.mark.parametrize("n_frames,w,h", [(8, 1920, 1080), (5, 1920, 1080), (3, 1280, 720), (11, 1920, 1080)])
 def test_learned_unit_order_of_large_batches_keeps_every_frame(big, rtx, synth, n_frames, w, h):
     """A batch of frames hands its work units out in the order learnt from the batch before it; the sort of the units'
-    costs has three paths by the number of unit groups (up to 16 384, up to 32 768, beyond). Eight 1080p frames have
-    32 400 groups of primary-ray units and about 29 000 of shadow units, five have 20 250, three 720p frames 5 400. Whatever
-    the path, an order that lost or repeated a group would leave pixels unrendered or rays uncounted: the batch is
+    costs has two paths by the number of unit groups (up to 16 384 in registers, beyond that in two passes). Eight 1080p
+    frames have 32 400 groups of primary-ray units and about 29 000 of shadow units, five have 20 250, three 720p frames
+    5 400, eleven 1080p frames (which need a larger ray batch than the default 16 Mi) 44 550. Whatever the path, an order that lost or repeated a group would leave pixels unrendered or rays uncounted: the batch is
     rendered three times (index order, then two learnt orders) and frames of the last one are compared with the same
     cameras rendered alone."""
     import torch
     flat, ctx = big
+    large = n_frames * w * h > (1 << 24)
+    if large:
+        ctx.set_option("batch_pixels", 3 << 23)
     cams = synth.camera_path(flat, 40, n_frames)
     batch = torch.full((n_frames * h * w * 3,), 7, dtype=torch.uint8, device="cuda:0")
     one = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda:0")
@@ -191,6 +194,8 @@ def test_learned_unit_order_of_large_batches_keeps_every_frame(big, rtx, synth, 
         nodes += st.shaded_nodes
         assert torch.equal(batch[k * h * w * 3:(k + 1) * h * w * 3], one), "frame %d" % k
     assert (shadow, nodes) == (stats[2].shadow_rays, stats[2].shaded_nodes)
+    if large:
+        ctx.set_option("batch_pixels", 1 << 24)
 
 
 def test_frames_in_flight(big, rtx, synth):
