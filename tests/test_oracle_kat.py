@@ -148,6 +148,31 @@ def test_scene_intersect_colour(orc):   # src/scene/mod.rs:270-281: one red sphe
     assert tuple(out["rgb"][1, 1]) == (255, 0, 0)
 
 
+def test_scene_intersect_keeps_the_first_hit_even_if_it_is_nan(orc):
+    """src/scene/mod.rs:188-192 takes the first Hit unconditionally and replaces it only on `new_point < point`. A ray with a
+    NaN direction -- Light::get_dir of a point that IS the light normalises a zero vector, scene/mod.rs:35-59 -- misses every
+    triangle (`t > 1e-7` is false, poly.rs:176) and gets Hit(NaN) from every sphere (no comparison of sphere.rs:70-102 is
+    true), so the loop returns the scene's first sphere, whatever lies where. The oracle restates that; the library documents
+    that it ignores Hit(NaN) instead (a shadow ray that starts at a point light sees the light there, not the first sphere)."""
+    f = orc.FlatScene()
+    f.tri_pos = np.array([[[-1, -1, -3], [1, -1, -3], [0, 1, -3]]], np.float32)
+    f.tri_mat = np.array([[0, 0xFFFFFFFF, 0xFFFFFFFF]], np.uint32)      # materials[0] only (RTX_MATERIAL_NONE elsewhere)
+    f.sph_center_radius = np.array([[50, 50, 50, 1], [0, 0, -5, 1]], np.float32)
+    f.sph_mat = np.array([0, 0], np.uint32)
+    f.materials = np.zeros((1,), orc.MATERIAL_DTYPE)
+    f.set_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 0.5)
+    s = orc.OracleScene.from_flat(f)
+    nan = float("nan")
+    prim, t = s.intersect_batch([[0, 0, 0], [0, 0, 0]], [[nan, nan, nan], [0, 0, -1]])
+    assert prim[0] == 1 and np.isnan(t[0])        # primitive 1 = the first sphere, nowhere near the origin
+    assert prim[1] == 0 and t[1] == 3.0           # the same scene with a real ray: the triangle in front
+    g = orc.FlatScene()
+    g.tri_pos, g.tri_mat, g.materials = f.tri_pos, f.tri_mat, f.materials
+    g.set_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 0.5)
+    prim, _ = orc.OracleScene.from_flat(g).intersect_batch([[0, 0, 0]], [[nan, nan, nan]])
+    assert prim[0] == -1                          # without a sphere such a ray misses
+
+
 def test_parser_fixture_scene(orc):  # src/scene/parser/test/mod.rs:205-211
     s = orc.OracleScene.parse(GOLDEN_DIR + "/parser/testdata-scene.txt")
     c = s.counts()
